@@ -1,0 +1,108 @@
+"""ctypes binding of libsr3d.so (the C ABI declared in include/sr3d.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be
+resolved the import of the engine fails, and every wrapper raises
+``RuntimeError`` with ``sr3d_last_error()`` when a call returns non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr3d.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED = 0, 1, 2, 3
+ACT_CODE = {None: ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU}
+
+
+class Slice(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("Z", C.c_int32), ("Y", C.c_int32),
+                ("X", C.c_int32), ("stride", C.c_int32)]
+
+
+# every symbol include/sr3d.h declares: name -> (restype, argtypes)
+_P, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_DESC, _SL = C.POINTER(ConvDesc), C.POINTER(Slice)
+SYMBOLS = {
+    "sr3d_version": (_I, []),
+    "sr3d_last_error": (C.c_char_p, []),
+    "sr3d_packed_weight_bytes": (_SZ, [_DESC, _I]),
+    "sr3d_pack_weights": (_I, [_DESC, _I, _P, _P, _P, _P]),
+    "sr3d_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _I, _I, _P]),
+    "sr3d_gated_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "sr3d_conv3d_bwd_data": (_I, [_DESC, _SL, _I, _P, _SL, _I, _P]),
+    "sr3d_conv3d_bwd_weight_workspace_bytes": (_SZ, [_DESC, _I]),
+    "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P]),
+    "sr3d_bias_grad_workspace_bytes": (_SZ, [_I, _I, _LL]),
+    "sr3d_bias_grad": (_I, [_P, _I, _I, _LL, _P, _P, _P]),
+    "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _P]),
+    "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _P]),
+    "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sr3d_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sr3d_near_wall": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sr3d_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
+    "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
+    "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libsr3d.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C 3d-sr-micrometeorology_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {lib.sr3d_last_error().decode()}")
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t: torch.Tensor, what: str = "tensor") -> C.c_void_p:
+    """device pointer of a dense fp32 GPU tensor (None -> NULL)"""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU: the sr3d engine has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{what} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def slices(tensors, what="srcs"):
+    """(B,C,Z,Y,X) tensors (or (channels, None) pairs for 'no gradient wanted') -> Slice array"""
+    arr = (Slice * len(tensors))()
+    for i, t in enumerate(tensors):
+        if isinstance(t, tuple):
+            arr[i].ptr, arr[i].channels = None, int(t[0])
+        else:
+            arr[i].ptr, arr[i].channels = dev_ptr(t, f"{what}[{i}]").value, int(t.shape[1])
+    return arr
+
+
+def conv_desc(B, Cin, Cout, Z, Y, X, stride) -> ConvDesc:
+    return ConvDesc(int(B), int(Cin), int(Cout), int(Z), int(Y), int(X), int(stride))

@@ -1,0 +1,72 @@
+// Shared device/host declarations for libsr3d (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sr3d.h"
+
+#define SR3D_MAX_SRC 4
+#define SR3D_MAX_TAPS 27
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A virtual channel-concatenation of up to 4 NCDHW fp32 tensors that share B and
+// the spatial grid.  cbeg[i] .. cbeg[i+1] are the concat channels of tensor i;
+// unused entries have cbeg = INT_MAX.  ptr may be null for a write destination
+// that does not need a gradient.
+struct ChanCat {
+  float* ptr[SR3D_MAX_SRC];
+  long long bstride[SR3D_MAX_SRC];  // elements between batch samples (= channels * Z*Y*X)
+  int cbeg[SR3D_MAX_SRC + 1];
+  int n;
+};
+
+void sr3d_set_error(const char* fmt, ...);
+
+#define SR3D_CHECK(cond, code, ...)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      sr3d_set_error(__VA_ARGS__);         \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+#define SR3D_HIP(call)                                                        \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      sr3d_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
+      return SR3D_E_HIP;                                                      \
+    }                                                                         \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channels, ChanCat* out, const char* what);
+
+__device__ __forceinline__ int cat_find(const ChanCat& c, int ch) {
+  return (ch >= c.cbeg[1]) + (ch >= c.cbeg[2]) + (ch >= c.cbeg[3]);
+}
+__device__ __forceinline__ float* cat_ptr(const ChanCat& c, int si) {
+  float* p = c.ptr[0];
+  p = si == 1 ? c.ptr[1] : p;
+  p = si == 2 ? c.ptr[2] : p;
+  p = si == 3 ? c.ptr[3] : p;
+  return p;
+}
+__device__ __forceinline__ long long cat_bstride(const ChanCat& c, int si) {
+  long long p = c.bstride[0];
+  p = si == 1 ? c.bstride[1] : p;
+  p = si == 2 ? c.bstride[2] : p;
+  p = si == 3 ? c.bstride[3] : p;
+  return p;
+}
+__device__ __forceinline__ int cat_cbeg(const ChanCat& c, int si) {
+  int p = c.cbeg[0];
+  p = si == 1 ? c.cbeg[1] : p;
+  p = si == 2 ? c.cbeg[2] : p;
+  p = si == 3 ? c.cbeg[3] : p;
+  return p;
+}

@@ -1,0 +1,313 @@
+// HBM-bound helper kernels of the voxel-SR hot path (gfx950): activation
+// backward, voxel shuffle backward, nearest-upsample+concat, mask pyramid,
+// near-wall mask, fused Adam.  All are streaming kernels: 16 B per lane where the
+// layout allows, one pass over the data, no LDS.
+#include "sr3d_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int blocks_for(long long n, int per_thread = 1) {
+  long long b = (n + (long long)kThreads * per_thread - 1) / ((long long)kThreads * per_thread);
+  const long long cap = 256 * 16;  // 16 workgroups per CU, grid-stride beyond that
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// derivative of the activation expressed through its OUTPUT f = act(pre)
+__device__ __forceinline__ float act_slope(float f, int act) {
+  if (act == SR3D_ACT_RELU) return f > 0.f ? 1.f : 0.f;
+  if (act == SR3D_ACT_LRELU) return f > 0.f ? 1.f : 0.01f;
+  return 1.f;
+}
+
+// d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)
+__global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const float* __restrict__ dy,
+                                                                 const float* __restrict__ f,
+                                                                 const float* __restrict__ s, float* __restrict__ df,
+                                                                 float* __restrict__ dg, long long n, int act) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = i0; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(dy)[i];
+    const float4 ff = reinterpret_cast<const float4*>(f)[i];
+    const float4 ss = reinterpret_cast<const float4*>(s)[i];
+    float4 o1, o2;
+#define ONE(q)                                                          \
+  o1.q = a.q * ss.q * act_slope(ff.q, act);                              \
+  o2.q = a.q * ff.q * (ss.q * (1.f - ss.q));
+    ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+    reinterpret_cast<float4*>(df)[i] = o1;
+    reinterpret_cast<float4*>(dg)[i] = o2;
+  }
+  for (long long i = n4 * 4 + i0; i < n; i += stride) {
+    const float a = dy[i], ff = f[i], ss = s[i];
+    df[i] = a * ss * act_slope(ff, act);
+    dg[i] = a * ff * (ss * (1.f - ss));
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             float* __restrict__ dp, long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = i0; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(dy)[i];
+    const float4 yy = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = yy.x > 0.f ? a.x : 0.01f * a.x;
+    o.y = yy.y > 0.f ? a.y : 0.01f * a.y;
+    o.z = yy.z > 0.f ? a.z : 0.01f * a.z;
+    o.w = yy.w > 0.f ? a.w : 0.01f * a.w;
+    reinterpret_cast<float4*>(dp)[i] = o;
+  }
+  for (long long i = n4 * 4 + i0; i < n; i += stride) dp[i] = y[i] > 0.f ? dy[i] : 0.01f * dy[i];
+}
+
+// dpre[b][f*C + c][z][y][x] = dy[b][c][2z+fz][2y+fy][2x+fx] * lrelu'(y[same])
+// one thread per (b, c, fine z, fine y, coarse x): reads a float2 (fx = 0, 1), writes two channels
+__global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const float* __restrict__ dy,
+                                                                       const float* __restrict__ y,
+                                                                       float* __restrict__ dp, int B, int C, int Z,
+                                                                       int Y, int X) {
+  const long long total = (long long)B * C * (2 * Z) * (2 * Y) * X;
+  const long long czyx = (long long)Z * Y * X;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int x = (int)(r % X);
+    r /= X;
+    const int fy_ = (int)(r % (2 * Y));
+    r /= 2 * Y;
+    const int fz_ = (int)(r % (2 * Z));
+    r /= 2 * Z;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    const float2 g = reinterpret_cast<const float2*>(dy)[i];
+    const float2 v = reinterpret_cast<const float2*>(y)[i];
+    const int fz = fz_ & 1, z = fz_ >> 1, fy = fy_ & 1, yy = fy_ >> 1;
+    const int f0 = (fz * 2 + fy) * 2;
+    const long long o = (((long long)b * 8 * C + (long long)f0 * C + c) * Z + z) * Y * X + (long long)yy * X + x;
+    dp[o] = v.x > 0.f ? g.x : 0.01f * g.x;
+    dp[o + (long long)C * czyx] = v.y > 0.f ? g.y : 0.01f * g.y;
+  }
+}
+
+// x0[b][c][z][y][x] = c < C ? x[b][c][z/s][y/s][x/s] : mask[b][0][z][y][x]
+__global__ __launch_bounds__(kThreads) void upsample_cat_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ m, float* __restrict__ out,
+                                                                int B, int C, int Z, int Y, int X, int s) {
+  const long long total = (long long)B * (C + 1) * Z * Y * X;
+  const int zl = Z / s, yl = Y / s, xl = X / s;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int xx = (int)(r % X);
+    r /= X;
+    const int yy = (int)(r % Y);
+    r /= Y;
+    const int zz = (int)(r % Z);
+    r /= Z;
+    const int c = (int)(r % (C + 1));
+    const int b = (int)(r / (C + 1));
+    float v;
+    if (c < C)
+      v = x[((((long long)b * C + c) * zl + zz / s) * yl + yy / s) * xl + xx / s];
+    else
+      v = m[(((long long)b * Z + zz) * Y + yy) * X + xx];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int B, int Z, int Y, int X) {
+  const int oz = Z / 2, oy = Y / 2, ox = X / 2;
+  const long long total = (long long)B * oz * oy * ox;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int xx = (int)(r % ox);
+    r /= ox;
+    const int yy = (int)(r % oy);
+    r /= oy;
+    const int zz = (int)(r % oz);
+    const int b = (int)(r / oz);
+    const float* p = in + (((long long)b * Z + 2 * zz) * Y + 2 * yy) * X + 2 * xx;
+    const long long sy = X, sz = (long long)Y * X;
+    float s = 0.f;
+    s += p[0] + p[1];
+    s += p[sy] + p[sy + 1];
+    s += p[sz] + p[sz + 1];
+    s += p[sz + sy] + p[sz + sy + 1];
+    out[i] = s * 0.125f;
+  }
+}
+
+// near = 1[ (sum over the zero-padded 3x3x3 box of (1 - b) > 0) * b > 0 ]
+__global__ __launch_bounds__(kThreads) void near_wall_kernel(const float* __restrict__ m, float* __restrict__ near,
+                                                             int B, int Z, int Y, int X) {
+  const long long total = (long long)B * Z * Y * X;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int xx = (int)(r % X);
+    r /= X;
+    const int yy = (int)(r % Y);
+    r /= Y;
+    const int zz = (int)(r % Z);
+    const int b = (int)(r / Z);
+    const float* p = m + (long long)b * Z * Y * X;
+    float s = 0.f;
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int z = zz + dz, y = yy + dy, x = xx + dx;
+          if ((unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)x < (unsigned)X)
+            s += 1.f - p[((long long)z * Y + y) * X + x];
+        }
+    const float filt = s > 0.f ? 1.f : 0.f;
+    near[i] = (filt * m[i] > 0.f) ? 1.f : 0.f;
+  }
+}
+
+// torch.optim.Adam (single-tensor path): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
+__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        float step_size, float inv_bc2_sqrt, float b1, float b2,
+                                                        float eps, float gscale) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float w1 = 1.f - b1, w2 = 1.f - b2;
+  for (long long i = i0; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ONE(q)                                              \
+  {                                                         \
+    const float gr = gg.q * gscale;                         \
+    mm.q = mm.q + w1 * (gr - mm.q);                         \
+    vv.q = vv.q * b2 + w2 * gr * gr;                        \
+    const float den = sqrtf(vv.q) * inv_bc2_sqrt + eps;     \
+    pp.q = pp.q - step_size * (mm.q / den);                 \
+  }
+    ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (long long i = n4 * 4 + i0; i < n; i += stride) {
+    const float gr = g[i] * gscale;
+    const float mm = m[i] + w1 * (gr - m[i]);
+    const float vv = v[i] * b2 + w2 * gr * gr;
+    const float den = sqrtf(vv) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mm / den);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+}  // namespace
+
+#define SR3D_ALIGN_CHECK(ptr, what) \
+  SR3D_CHECK((reinterpret_cast<uintptr_t>(ptr) & 15) == 0, SR3D_E_ARG, what ": pointer must be 16-byte aligned")
+
+extern "C" {
+
+int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
+                       long long n, int act, void* stream) {
+  SR3D_CHECK(dy && save_f && save_s && d_feat && d_gate && n > 0, SR3D_E_ARG, "gated_act_bwd: bad argument");
+  SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_act_bwd: unknown activation %d", act);
+  SR3D_ALIGN_CHECK(dy, "gated_act_bwd");
+  SR3D_ALIGN_CHECK(save_f, "gated_act_bwd");
+  SR3D_ALIGN_CHECK(save_s, "gated_act_bwd");
+  SR3D_ALIGN_CHECK(d_feat, "gated_act_bwd");
+  SR3D_ALIGN_CHECK(d_gate, "gated_act_bwd");
+  hipLaunchKernelGGL(gated_act_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)dy, (const float*)save_f, (const float*)save_s, (float*)d_feat, (float*)d_gate, n,
+                     act);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, void* stream) {
+  SR3D_CHECK(dy && y && dpre && n > 0, SR3D_E_ARG, "lrelu_bwd: bad argument");
+  SR3D_ALIGN_CHECK(dy, "lrelu_bwd");
+  SR3D_ALIGN_CHECK(y, "lrelu_bwd");
+  SR3D_ALIGN_CHECK(dpre, "lrelu_bwd");
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)dy, (const float*)y, (float*)dpre, n);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X,
+                             void* stream) {
+  SR3D_CHECK(dy && y && dpre && B > 0 && C > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG,
+             "unshuffle_lrelu_bwd: bad argument");
+  SR3D_CHECK((reinterpret_cast<uintptr_t>(dy) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, SR3D_E_ARG,
+             "unshuffle_lrelu_bwd: pointers must be 8-byte aligned");
+  const long long total = (long long)B * C * 4 * Z * Y * X;
+  hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)dy, (const float*)y, (float*)dpre, B, C, Z, Y, X);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_upsample_cat(const void* x, const void* b, void* x0, int B, int C, int Z, int Y, int X, int scale,
+                      void* stream) {
+  SR3D_CHECK(x && b && x0 && B > 0 && C > 0 && Z > 0 && Y > 0 && X > 0 && scale >= 1, SR3D_E_ARG,
+             "upsample_cat: bad argument");
+  SR3D_CHECK(Z % scale == 0 && Y % scale == 0 && X % scale == 0, SR3D_E_ARG,
+             "upsample_cat: grid (%d,%d,%d) is not a multiple of the scale %d", Z, Y, X, scale);
+  const long long total = (long long)B * (C + 1) * Z * Y * X;
+  hipLaunchKernelGGL(upsample_cat_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)x, (const float*)b, (float*)x0, B, C, Z, Y, X, scale);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_avgpool2(const void* in, void* out, int B, int Z, int Y, int X, void* stream) {
+  SR3D_CHECK(in && out && B > 0 && Z >= 2 && Y >= 2 && X >= 2, SR3D_E_ARG, "avgpool2: bad argument");
+  const long long total = (long long)B * (Z / 2) * (Y / 2) * (X / 2);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)in, (float*)out, B, Z, Y, X);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* stream) {
+  SR3D_CHECK(b && near && B > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG, "near_wall: bad argument");
+  const long long total = (long long)B * Z * Y * X;
+  hipLaunchKernelGGL(near_wall_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)b, (float*)near, B, Z, Y, X);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, void* stream) {
+  SR3D_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, SR3D_E_ARG, "adam_step: bad argument");
+  SR3D_ALIGN_CHECK(param, "adam_step");
+  SR3D_ALIGN_CHECK(grad, "adam_step");
+  SR3D_ALIGN_CHECK(exp_avg, "adam_step");
+  SR3D_ALIGN_CHECK(exp_avg_sq, "adam_step");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
+                     (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt, beta1, beta2,
+                     eps, grad_scale);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+}  // extern "C"

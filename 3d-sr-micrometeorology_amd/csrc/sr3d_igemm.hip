@@ -1,0 +1,549 @@
+// Implicit-GEMM 3x3x3 Conv3d for gfx950 on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   D[n][m] = sum_{tap t, channel c} Wp[t][c][n] * In[c][ m shifted by tap t ]
+//
+//   rows  n : output channels (A operand = packed weights, staged in LDS by LDS-DMA)
+//   cols  m : output voxels   (B operand = an LDS halo tile of the input, x on the lanes)
+//   K       : (tap, channel), channels in chunks of KC
+//
+// One kernel serves the forward conv (stride 1/2), the stride-1 input gradient
+// (same loop, transposed weight image, mirrored tap list) and the stride-2
+// input gradient (8 parity classes, each a small conv over the coarse grid with
+// 1/2/4/8 taps whose result is written to every second voxel).  The input is a
+// *virtual* channel concatenation of up to 4 tensors, so torch.cat
+// (reference unet.py:255-293) is never materialised.  Epilogues: bias +
+// activation, gate (sigmoid * act) with the tensors the backward needs, and
+// the voxel-unshuffle scatter (voxel_shuffle.py:26-42).
+#include "sr3d_common.h"
+
+#include <limits.h>
+
+namespace {
+
+enum { EPI_PLAIN = 0, EPI_GATED = 1, EPI_UNSHUFFLE = 2 };
+
+struct IgemmParams {
+  ChanCat in;          // K side (channels of the virtual concat)
+  int K;               // valid input channels
+  int IZ, IY, IX;      // input grid
+  int OZ, OY, OX;      // o-space (tile space) grid
+  int ntz, nty, ntx;   // tiles per dim
+  int ntaps;
+  int tap_off[SR3D_MAX_TAPS];  // float offset of each tap inside one channel of the halo tile
+  const float* wp;     // packed weights [nblk][chunk][tap][KC][BN]
+  int nchunks;
+  int N;               // valid rows
+  int epi, act;
+  const float* bias;   // plain/unshuffle: bias[n];  gated: feature bias (may be null)
+  const float* bias2;  // gated: gate bias
+  ChanCat out;         // plain: destination concat (rows n are concat channels)
+  float* y;            // gated / unshuffle output
+  float* save_f;
+  float* save_s;
+  int TZ_, TY_, TX_;   // destination tensor grid
+  int s_out, pz, py, px;
+  int unsh_C;          // unshuffle: channels of the result (= N / 8)
+  int Cg;              // gated: width of one branch (channels of y / save_f / save_s)
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
+struct IgemmCfg {
+  static constexpr int TX = 32;
+  static constexpr int HZ = (TZ - 1) * S_IN + (HI - LO) + 1;
+  static constexpr int HY = (TY - 1) * S_IN + (HI - LO) + 1;
+  static constexpr int HX = (TX - 1) * S_IN + (HI - LO) + 1;
+  static constexpr int HCH = HZ * HY * HX;
+  static constexpr int HS = (KC * HCH + 3) & ~3;  // floats, keeps the weight image 16-B aligned
+  static constexpr int WM = 4 / WN;
+  static constexpr int RT = BN / WN / 32;
+  static constexpr int CT = TZ * TY / WM;
+  static constexpr size_t lds_bytes(int ntaps) { return (size_t)(HS + ntaps * KC * BN) * 4; }
+  static_assert(TZ * TY % WM == 0, "col tiles must split over waves");
+  static_assert(BN % (WN * 32) == 0, "row tiles must split over waves");
+};
+
+template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
+  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, RT = C::RT, CT = C::CT, WM = C::WM;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Hs = lds;
+  float* Ws = lds + C::HS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / WM, wm = wave % WM;
+
+  int tile = blockIdx.x;
+  const int tix = tile % p.ntx;
+  tile /= p.ntx;
+  const int tiy = tile % p.nty;
+  const int tiz = tile / p.nty;
+  const int nblk = blockIdx.y;
+  const int b = blockIdx.z;
+  const int oz0 = tiz * TZ, oy0 = tiy * TY, ox0 = tix * 32;
+  const int gz0 = oz0 * S_IN + LO, gy0 = oy0 * S_IN + LO, gx0 = ox0 * S_IN + LO;
+  const long long IZYX = (long long)p.IZ * p.IY * p.IX;
+
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int a_lane = (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
+  const int b_lane = (lane >> 5) * HCH + (lane & 31) * S_IN;
+  int b_ct[CT];
+#pragma unroll
+  for (int j = 0; j < CT; j++) {
+    const int ct = wm * CT + j;
+    b_ct[j] = ((ct / TY) * S_IN * HY + (ct % TY) * S_IN) * HX + b_lane;
+  }
+  // spatial offsets of this thread's halo elements (independent of the chunk); -1 = outside the grid
+  constexpr int NI = (HCH + 255) / 256;
+  int hoff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int r = tid + i * 256;
+    const int hz = r / (HY * HX);
+    const int r2 = r - hz * (HY * HX);
+    const int hy = r2 / HX;
+    const int hx = r2 - hy * HX;
+    const int gz = gz0 + hz, gy = gy0 + hy, gx = gx0 + hx;
+    const bool ok = r < HCH && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY &&
+                    (unsigned)gx < (unsigned)p.IX;
+    hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
+  }
+  const int wblock = p.ntaps * KC * BN;  // floats per (nblk, chunk)
+  const int ninstr = wblock / 256;       // 1 KiB LDS-DMA pieces
+
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    // ---- weights: contiguous block, asynchronous global -> LDS (no VGPRs)
+    {
+      const float* gw = p.wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
+      for (int i = wave; i < ninstr; i += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(Ws + i * 256), 16, 0, 0);
+    }
+    // ---- input halo tile [KC][HZ][HY][HX], zero outside the grid / beyond K.
+    // The channel is wave-uniform (scalar source select), the spatial offsets
+    // were computed once before the chunk loop.
+    {
+      float v[KC][NI];
+#pragma unroll
+      for (int c = 0; c < KC; c++) {
+        const int gc = chunk * KC + c;
+        const float* base = nullptr;
+        if (gc < p.K) {
+          const int si = cat_find(p.in, gc);
+          base = p.in.ptr[si] + (long long)b * p.in.bstride[si] + (long long)(gc - p.in.cbeg[si]) * IZYX;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[c][i] = (base != nullptr && hoff[i] >= 0) ? base[hoff[i]] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < KC; c++)
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+          if (tid + i * 256 < HCH) Hs[c * HCH + tid + i * 256] = v[c][i];
+    }
+    __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA has landed)
+
+    for (int t = 0; t < p.ntaps; t++) {
+      const float* wt = Ws + t * (KC * BN) + a_lane;
+      const float* ht = Hs + p.tap_off[t];
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; kk++) {
+        float a[RT], bb[CT];
+#pragma unroll
+        for (int i = 0; i < RT; i++) a[i] = wt[(2 * kk) * BN + i * 32];
+#pragma unroll
+        for (int j = 0; j < CT; j++) bb[j] = ht[(2 * kk) * HCH + b_ct[j]];
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+          for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int ox = ox0 + (lane & 31);
+  const int nrow0 = nblk * BN + wn * (BN / WN) + 4 * (lane >> 5);
+  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
+
+  if (p.epi == EPI_GATED) {
+    // row tiles come in (feature, gate) pairs of the same 32 channels
+    if constexpr (RT % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < CT; j++) {
+        const int ct = wm * CT + j;
+        const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
+        if (oz >= p.OZ || oy >= p.OY || ox >= p.OX) continue;
+        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+#pragma unroll
+        for (int i = 0; i < RT; i += 2) {
+          const int cbase = (nblk * BN + wn * (BN / WN) + i * 32) / 2 + 4 * (lane >> 5);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int co = cbase + (r & 3) + 8 * (r >> 2);
+            if (co < p.Cg) {
+              float f = acc[i][j][r];
+              if (p.bias) f += p.bias[co];
+              const float g = acc[i + 1][j][r] + (p.bias2 ? p.bias2[co] : 0.f);
+              const float s = 1.f / (1.f + expf(-g));
+              f = act_apply(f, p.act);
+              const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+              p.y[o] = s * f;
+              if (p.save_f) {
+                p.save_f[o] = f;
+                p.save_s[o] = s;
+              }
+            }
+          }
+        }
+      }
+    }
+  } else if (p.epi == EPI_UNSHUFFLE) {
+#pragma unroll
+    for (int j = 0; j < CT; j++) {
+      const int ct = wm * CT + j;
+      const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
+      if (oz >= p.OZ || oy >= p.OY || ox >= p.OX) continue;
+#pragma unroll
+      for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int n = nrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (n < p.N) {
+            const float v = act_apply(acc[i][j][r] + p.bias[n], p.act);
+            const int f = n / p.unsh_C, c = n - f * p.unsh_C;
+            const long long o = ((long long)b * p.unsh_C + c) * TZYX +
+                                ((long long)(2 * oz + (f >> 2)) * p.TY_ + (2 * oy + ((f >> 1) & 1))) * p.TX_ +
+                                (2 * ox + (f & 1));
+            p.y[o] = v;
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = nrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (n >= p.N) continue;
+        const int si = cat_find(p.out, n);
+        float* base = cat_ptr(p.out, si);
+        if (base == nullptr) continue;
+        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+          const int ct = wm * CT + j;
+          const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
+          if (oz < p.OZ && oy < p.OY && ox < p.OX) {
+            const long long sp = ((long long)(oz * p.s_out + p.pz) * p.TY_ + (oy * p.s_out + p.py)) * p.TX_ +
+                                 (ox * p.s_out + p.px);
+            base[sp] = act_apply(acc[i][j][r] + bv, p.act);
+          }
+        }
+      }
+  }
+}
+
+// --------------------------------------------------------------------- packing
+struct PackParams {
+  const float* w1;
+  const float* w2;
+  float* wp;
+  int Cout, Cin;  // of the physical (Cout, Cin, 27) tensors
+  int kind;
+  int K, N;       // logical GEMM dims
+  int nchunks, nblk, BN, KC;
+  int ntaps;
+  int tap[SR3D_MAX_TAPS];  // original tap index (kz*3+ky)*3+kx of packed tap t
+};
+
+__global__ void pack_kernel(const PackParams p) {
+  const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    long long r = e;
+    const int nn = r % p.BN;
+    r /= p.BN;
+    const int kc = r % p.KC;
+    r /= p.KC;
+    const int t = r % p.ntaps;
+    r /= p.ntaps;
+    const int chunk = r % p.nchunks;
+    const int nb = r / p.nchunks;
+    const int n = nb * p.BN + nn, k = chunk * p.KC + kc;
+    float v = 0.f;
+    if (n < p.N && k < p.K) {
+      const int tap = p.tap[t];
+      if (p.kind == SR3D_PACK_FWD) {
+        v = p.w1[((long long)n * p.Cin + k) * 27 + tap];
+      } else if (p.kind == SR3D_PACK_FWD_GATED) {
+        const int blk = n >> 5;
+        const int co = (blk >> 1) * 32 + (n & 31);
+        if (co < p.Cout) v = ((blk & 1) ? p.w2 : p.w1)[((long long)co * p.Cin + k) * 27 + tap];
+      } else if (p.kind == SR3D_PACK_BWD) {
+        v = p.w1[((long long)k * p.Cin + n) * 27 + tap];
+      } else {
+        v = (k < p.Cout ? p.w1 + (long long)k * p.Cin * 27 : p.w2 + (long long)(k - p.Cout) * p.Cin * 27)[n * 27 + tap];
+      }
+    }
+    p.wp[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+constexpr int kBN = 128, kKC = 4;
+
+struct Geometry {
+  int K, N, nblk, nchunks;
+};
+
+inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
+
+Geometry geometry(const sr3d_conv_desc_t* d, int kind) {
+  Geometry g;
+  switch (kind) {
+    case SR3D_PACK_FWD: g.K = d->Cin, g.N = d->Cout; break;
+    case SR3D_PACK_FWD_GATED: g.K = d->Cin, g.N = 2 * ((d->Cout + 31) / 32) * 32; break;
+    case SR3D_PACK_BWD: g.K = d->Cout, g.N = d->Cin; break;
+    default: g.K = 2 * d->Cout, g.N = d->Cin; break;
+  }
+  g.nblk = ceil_div(g.N, kBN);
+  g.nchunks = ceil_div(g.K, kKC);
+  return g;
+}
+
+// stride-2 backward: taps of parity class (pz,py,px), in (kz,ky,kx) order
+int class_taps(int cls, int* orig, int* dz, int* dy, int* dx) {
+  const int par[3] = {(cls >> 2) & 1, (cls >> 1) & 1, cls & 1};
+  int k[3][2], dd[3][2], cnt[3];
+  for (int a = 0; a < 3; a++) {
+    if (par[a] == 0) {
+      cnt[a] = 1, k[a][0] = 1, dd[a][0] = 0;
+    } else {
+      cnt[a] = 2, k[a][0] = 0, dd[a][0] = 1, k[a][1] = 2, dd[a][1] = 0;
+    }
+  }
+  int n = 0;
+  for (int a = 0; a < cnt[0]; a++)
+    for (int bb = 0; bb < cnt[1]; bb++)
+      for (int c = 0; c < cnt[2]; c++) {
+        orig[n] = (k[0][a] * 3 + k[1][bb]) * 3 + k[2][c];
+        dz[n] = dd[0][a], dy[n] = dd[1][bb], dx[n] = dd[2][c];
+        n++;
+      }
+  return n;
+}
+
+size_t class_offset_floats(const Geometry& g, int cls) {
+  // packed images of the 8 parity classes are stored back to back
+  size_t off = 0;
+  int o[27], a[27], b[27], c[27];
+  for (int i = 0; i < cls; i++) off += (size_t)g.nblk * g.nchunks * class_taps(i, o, a, b, c) * kKC * kBN;
+  return off;
+}
+
+template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
+int launch(IgemmParams& p, int B, hipStream_t st) {
+  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
+  p.ntz = ceil_div(p.OZ, TZ), p.nty = ceil_div(p.OY, TY), p.ntx = ceil_div(p.OX, 32);
+  auto kern = igemm_kernel<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
+  const size_t lds = C::lds_bytes(p.ntaps);
+  static thread_local size_t configured = 0;
+  if (lds > configured) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  dim3 grid(p.ntz * p.nty * p.ntx, ceil_div(p.N, BN), B);
+  SR3D_CHECK(grid.y <= 65535 && grid.z <= 65535, SR3D_E_ARG, "igemm: grid too large");
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+void full_taps(IgemmParams& p, int HY, int HX, bool mirrored) {
+  p.ntaps = 27;
+  for (int kz = 0; kz < 3; kz++)
+    for (int ky = 0; ky < 3; ky++)
+      for (int kx = 0; kx < 3; kx++) {
+        const int t = (kz * 3 + ky) * 3 + kx;
+        // forward: input offset d = k-1 -> (d-LO) = k ; stride-1 backward: d = 1-k -> (d-LO) = 2-k
+        const int a = mirrored ? 2 - kz : kz, b = mirrored ? 2 - ky : ky, c = mirrored ? 2 - kx : kx;
+        p.tap_off[t] = (a * HY + b) * HX + c;
+      }
+}
+
+int check_desc(const sr3d_conv_desc_t* d) {
+  SR3D_CHECK(d != nullptr, SR3D_E_ARG, "conv desc is null");
+  SR3D_CHECK(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Z > 0 && d->Y > 0 && d->X > 0, SR3D_E_ARG,
+             "conv desc: non-positive dimension");
+  SR3D_CHECK(d->stride == 1 || d->stride == 2, SR3D_E_ARG, "conv desc: stride must be 1 or 2 (got %d)", d->stride);
+  SR3D_CHECK((long long)d->Z * d->Y * d->X < (1ll << 31), SR3D_E_ARG, "conv desc: grid has >= 2^31 voxels");
+  return SR3D_OK;
+}
+
+int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, IgemmParams& p, int dst_scale,
+                   hipStream_t st) {
+  const long long vox = (long long)d->Z * d->Y * d->X;
+  if (int rc = sr3d_make_cat(x_srcs, n_src, vox, d->Cin, &p.in, "x_srcs")) return rc;
+  for (int i = 0; i < p.in.n; i++) SR3D_CHECK(p.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+  p.K = d->Cin;
+  p.IZ = d->Z, p.IY = d->Y, p.IX = d->X;
+  p.OZ = out_dim(d->Z, d->stride), p.OY = out_dim(d->Y, d->stride), p.OX = out_dim(d->X, d->stride);
+  p.TZ_ = p.OZ * dst_scale, p.TY_ = p.OY * dst_scale, p.TX_ = p.OX * dst_scale;
+  p.s_out = 1, p.pz = p.py = p.px = 0;
+  p.nchunks = ceil_div(p.K, kKC);
+  if (d->stride == 1) {
+    using C = IgemmCfg<1, -1, 1, 2, 4, kBN, 2, kKC>;
+    full_taps(p, C::HY, C::HX, false);
+    return launch<1, -1, 1, 2, 4, kBN, 2, kKC>(p, d->B, st);
+  }
+  using C = IgemmCfg<2, -1, 1, 1, 4, kBN, 2, kKC>;
+  full_taps(p, C::HY, C::HX, false);
+  return launch<2, -1, 1, 1, 4, kBN, 2, kKC>(p, d->B, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
+  if (check_desc(d) != SR3D_OK || kind < 0 || kind > 3) return 0;
+  const Geometry g = geometry(d, kind);
+  if ((kind == SR3D_PACK_BWD || kind == SR3D_PACK_BWD_GATED) && d->stride == 2) return class_offset_floats(g, 8) * 4;
+  return (size_t)g.nblk * g.nchunks * 27 * kKC * kBN * 4;
+}
+
+int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, const void* w_gate, void* w_packed,
+                      void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SR3D_CHECK(kind >= 0 && kind <= 3, SR3D_E_ARG, "pack: unknown kind %d", kind);
+  SR3D_CHECK(w_feat && w_packed, SR3D_E_ARG, "pack: null pointer");
+  const bool gated = kind == SR3D_PACK_FWD_GATED || kind == SR3D_PACK_BWD_GATED;
+  SR3D_CHECK(!gated || w_gate, SR3D_E_ARG, "pack: gated kind needs w_gate");
+  const Geometry g = geometry(d, kind);
+  PackParams p{};
+  p.w1 = (const float*)w_feat, p.w2 = (const float*)w_gate;
+  p.Cout = d->Cout, p.Cin = d->Cin, p.kind = kind, p.K = g.K, p.N = g.N;
+  p.nchunks = g.nchunks, p.nblk = g.nblk, p.BN = kBN, p.KC = kKC;
+  const bool bwd = kind == SR3D_PACK_BWD || kind == SR3D_PACK_BWD_GATED;
+  const int nimg = (bwd && d->stride == 2) ? 8 : 1;
+  for (int cls = 0; cls < nimg; cls++) {
+    int dz[27], dy[27], dx[27];
+    if (nimg == 8) {
+      p.ntaps = class_taps(cls, p.tap, dz, dy, dx);
+      p.wp = (float*)w_packed + class_offset_floats(g, cls);
+    } else {
+      p.ntaps = 27;
+      for (int t = 0; t < 27; t++) p.tap[t] = t;
+      p.wp = (float*)w_packed;
+    }
+    const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SR3D_HIP(hipGetLastError());
+  }
+  return SR3D_OK;
+}
+
+int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
+                    const void* bias, void* y, int act, int unshuffle, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SR3D_CHECK(w_packed && y, SR3D_E_ARG, "conv3d_fwd: null pointer");
+  SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "conv3d_fwd: unknown activation %d", act);
+  IgemmParams p{};
+  p.wp = (const float*)w_packed;
+  p.N = d->Cout;
+  p.act = act;
+  p.bias = (const float*)bias;
+  const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
+  if (unshuffle) {
+    SR3D_CHECK(d->Cout % 8 == 0, SR3D_E_ARG, "conv3d_fwd: unshuffle needs Cout %% 8 == 0 (got %d)", d->Cout);
+    SR3D_CHECK(bias != nullptr, SR3D_E_ARG, "conv3d_fwd: unshuffle epilogue expects a bias");
+    p.epi = EPI_UNSHUFFLE;
+    p.y = (float*)y;
+    p.unsh_C = d->Cout / 8;
+  } else {
+    p.epi = EPI_PLAIN;
+    sr3d_slice_t ys{y, d->Cout};
+    if (int rc = sr3d_make_cat(&ys, 1, (long long)OZ * OY * OX, d->Cout, &p.out, "y")) return rc;
+  }
+  if (unshuffle) SR3D_CHECK(d->stride == 1, SR3D_E_ARG, "conv3d_fwd: unshuffle epilogue is stride-1 only");
+  return forward_common(d, x_srcs, n_src, p, unshuffle ? 2 : 1, (hipStream_t)stream);
+}
+
+int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
+                          const void* bias_f, const void* bias_g, void* y, void* save_f, void* save_s, int act,
+                          void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SR3D_CHECK(w_packed && y, SR3D_E_ARG, "gated_conv3d_fwd: null pointer");
+  SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
+  SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_conv3d_fwd: unknown activation %d", act);
+  IgemmParams p{};
+  p.wp = (const float*)w_packed;
+  p.epi = EPI_GATED;
+  p.act = act;
+  p.bias = (const float*)bias_f, p.bias2 = (const float*)bias_g;
+  p.y = (float*)y, p.save_f = (float*)save_f, p.save_s = (float*)save_s;
+  p.N = geometry(d, SR3D_PACK_FWD_GATED).N;  // GEMM rows: feature/gate interleaved in blocks of 32
+  p.Cg = d->Cout;
+  return forward_common(d, x_srcs, n_src, p, 1, (hipStream_t)stream);
+}
+
+int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_packed_bwd,
+                         const sr3d_slice_t* dx_dsts, int n_dst, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  SR3D_CHECK(w_packed_bwd, SR3D_E_ARG, "conv3d_bwd_data: null weight image");
+  SR3D_CHECK(n_dy == 1 || n_dy == 2, SR3D_E_ARG, "conv3d_bwd_data: n_dy must be 1 or 2");
+  const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
+  const int kind = n_dy == 2 ? SR3D_PACK_BWD_GATED : SR3D_PACK_BWD;
+  const Geometry g = geometry(d, kind);
+  IgemmParams p{};
+  if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)OZ * OY * OX, g.K, &p.in, "dy_srcs")) return rc;
+  for (int i = 0; i < p.in.n; i++) SR3D_CHECK(p.in.ptr[i] != nullptr, SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+  if (int rc = sr3d_make_cat(dx_dsts, n_dst, (long long)d->Z * d->Y * d->X, d->Cin, &p.out, "dx_dsts")) return rc;
+  p.K = g.K, p.N = g.N, p.nchunks = g.nchunks;
+  p.IZ = OZ, p.IY = OY, p.IX = OX;
+  p.TZ_ = d->Z, p.TY_ = d->Y, p.TX_ = d->X;
+  p.epi = EPI_PLAIN, p.act = SR3D_ACT_NONE;
+  if (d->stride == 1) {
+    p.wp = (const float*)w_packed_bwd;
+    p.OZ = d->Z, p.OY = d->Y, p.OX = d->X;
+    p.s_out = 1;
+    using C = IgemmCfg<1, -1, 1, 2, 4, kBN, 2, kKC>;
+    full_taps(p, C::HY, C::HX, true);
+    return launch<1, -1, 1, 2, 4, kBN, 2, kKC>(p, d->B, (hipStream_t)stream);
+  }
+  using C = IgemmCfg<1, 0, 1, 2, 4, kBN, 2, kKC>;
+  for (int cls = 0; cls < 8; cls++) {
+    IgemmParams q = p;
+    int orig[27], dz[27], dy[27], dx[27];
+    q.ntaps = class_taps(cls, orig, dz, dy, dx);
+    for (int t = 0; t < q.ntaps; t++) q.tap_off[t] = (dz[t] * C::HY + dy[t]) * C::HX + dx[t];
+    q.wp = (const float*)w_packed_bwd + class_offset_floats(g, cls);
+    q.pz = (cls >> 2) & 1, q.py = (cls >> 1) & 1, q.px = cls & 1;
+    q.s_out = 2;
+    q.OZ = (d->Z - q.pz + 1) / 2, q.OY = (d->Y - q.py + 1) / 2, q.OX = (d->X - q.px + 1) / 2;
+    if (q.OZ <= 0 || q.OY <= 0 || q.OX <= 0) continue;
+    if (int rc = launch<1, 0, 1, 2, 4, kBN, 2, kKC>(q, d->B, (hipStream_t)stream)) return rc;
+  }
+  return SR3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// Fused training losses (forward value + dL/dprediction) for gfx950.
+//
+//  - MyL1Loss                         (reference pytorch/src/loss_maker.py:194-202)
+//  - MixedDivergenceGradientL2Loss    (loss_maker.py:358-450) with its helpers
+//    calc_mask_near_build_wall (:57-83), differentiate_along_{x,y,z}
+//    (math_helper.py:6-60, padding 0) and _calc_residual_continuity_eq (:115-130).
+//
+// The reference evaluates the mixed loss with ~40 elementwise launches and ten
+// 27-tap depthwise convolutions; here it is two stencil passes:
+//   pass 1  reads p, t, b once (neighbours through L1/L2), accumulates the four
+//           sums (sum d^2, sum M*|grad d|^2, sum M*dd^2, sum M) and stores the
+//           two per-voxel fields the adjoint needs (M and E = M*dd);
+//   pass 2  applies the adjoint of the two-tap stencils analytically and writes
+//           dL/dp.  Reductions are two-stage with a fixed order (deterministic).
+#include "sr3d_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  // wave64 shuffle reduction, then the 4 wave partials through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------- L1
+__global__ __launch_bounds__(kThreads) void l1_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                      long long n, float* __restrict__ part,
+                                                      float* __restrict__ dldp, float inv_n) {
+  __shared__ float red[4];
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  for (long long i = i0; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(p)[i];
+    const float4 b = reinterpret_cast<const float4*>(t)[i];
+    float4 g;
+#define ONE(q)                                               \
+  {                                                          \
+    const float d = a.q - b.q;                               \
+    s += fabsf(d);                                           \
+    g.q = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);        \
+  }
+    ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+    if (dldp) reinterpret_cast<float4*>(dldp)[i] = g;
+  }
+  for (long long i = n4 * 4 + i0; i < n; i += stride) {
+    const float d = p[i] - t[i];
+    s += fabsf(d);
+    if (dldp) dldp[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+  }
+  const float tot = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ void l1_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out, double inv_n) {
+  __shared__ double red[kThreads];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kThreads) s += (double)part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
+// ---------------------------------------------------------------- mixed loss
+struct MixParams {
+  const float* p;
+  const float* t;
+  const float* b;
+  int B, Z, Y, X;
+  float s[3];        // velocity scales (u, v, w)
+  float w_g, w_d;
+  float delta, mean_scale;
+  float* fieldM;     // [B][Z][Y][X]
+  float* fieldE;
+  float* part;       // [4][nblocks]
+  float* sums;       // 4 floats: sum d^2, grd numerator, div numerator, sum M
+  float* terms;      // out: mse, grd, div, total
+  float* dldp;
+};
+
+__device__ __forceinline__ float cdiff(float hi, float lo, float w) { return hi * w + lo * (-w); }
+
+__global__ __launch_bounds__(kThreads) void mix_pass1_kernel(const MixParams q) {
+  __shared__ float red[4];
+  const long long zyx = (long long)q.Z * q.Y * q.X;
+  const long long total = (long long)q.B * zyx;
+  const long long sy = q.X, sz = (long long)q.Y * q.X;
+  const float w5 = 1.f / (2.f * q.delta);
+  float a_mse = 0.f, a_grd = 0.f, a_div = 0.f, a_m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int x = (int)(r % q.X);
+    r /= q.X;
+    const int y = (int)(r % q.Y);
+    r /= q.Y;
+    const int z = (int)(r % q.Z);
+    const int b = (int)(r / q.Z);
+    const long long sp = i - (long long)b * zyx;
+    const float* P = q.p + (long long)b * 4 * zyx + sp;
+    const float* T = q.t + (long long)b * 4 * zyx + sp;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float d = P[c * zyx] - T[c * zyx];
+      a_mse += d * d;
+    }
+    float M = 0.f, E = 0.f;
+    const bool interior = x >= 1 && x < q.X - 1 && y >= 1 && y < q.Y - 1 && z >= 1 && z < q.Z - 1;
+    if (interior) {
+      const float* Bm = q.b + (long long)b * zyx + sp;
+      float box = 0.f;
+#pragma unroll
+      for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++) box += 1.f - Bm[dz * sz + dy * sy + dx];
+      const float bv = Bm[0];
+      const float near = ((box > 0.f ? 1.f : 0.f) * bv > 0.f) ? 1.f : 0.f;
+      M = bv * (1.f - near);
+      a_m += M;
+      if (q.w_g != 0.f) {
+        float g2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float* Pc = P + c * zyx;
+          const float* Tc = T + c * zyx;
+          const float gx = cdiff(Pc[1] - Tc[1], Pc[-1] - Tc[-1], 0.5f);
+          const float gy = cdiff(Pc[sy] - Tc[sy], Pc[-sy] - Tc[-sy], 0.5f);
+          const float gz = cdiff(Pc[sz] - Tc[sz], Pc[-sz] - Tc[-sz], 0.5f);
+          g2 += gx * gx + gy * gy + gz * gz;
+        }
+        a_grd += g2 * M;
+      }
+      if (q.w_d != 0.f) {
+        const float* Pu = P + 1 * zyx;
+        const float* Pv = P + 2 * zyx;
+        const float* Pw = P + 3 * zyx;
+        const float* Tu = T + 1 * zyx;
+        const float* Tv = T + 2 * zyx;
+        const float* Tw = T + 3 * zyx;
+        const float div_t = cdiff(q.s[0] * Tu[1], q.s[0] * Tu[-1], w5) + cdiff(q.s[1] * Tv[sy], q.s[1] * Tv[-sy], w5) +
+                            cdiff(q.s[2] * Tw[sz], q.s[2] * Tw[-sz], w5);
+        const float div_p = cdiff(q.s[0] * Pu[1], q.s[0] * Pu[-1], w5) + cdiff(q.s[1] * Pv[sy], q.s[1] * Pv[-sy], w5) +
+                            cdiff(q.s[2] * Pw[sz], q.s[2] * Pw[-sz], w5);
+        const float dd = (div_t - div_p) * q.delta / q.mean_scale;
+        a_div += dd * dd * M;
+        E = M * dd;
+      }
+    }
+    if (q.fieldM) {
+      q.fieldM[i] = M;
+      q.fieldE[i] = E;
+    }
+  }
+  const int nb = gridDim.x;
+  float v;
+  v = block_sum(a_mse, red);
+  if (threadIdx.x == 0) q.part[0 * nb + blockIdx.x] = v;
+  v = block_sum(a_grd, red);
+  if (threadIdx.x == 0) q.part[1 * nb + blockIdx.x] = v;
+  v = block_sum(a_div, red);
+  if (threadIdx.x == 0) q.part[2 * nb + blockIdx.x] = v;
+  v = block_sum(a_m, red);
+  if (threadIdx.x == 0) q.part[3 * nb + blockIdx.x] = v;
+}
+
+// one block: finish the four sums in double, emit the loss terms
+__global__ __launch_bounds__(kThreads) void mix_final_kernel(const MixParams q, int nb) {
+  __shared__ double red[kThreads];
+  double tot[4];
+  for (int k = 0; k < 4; k++) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kThreads) s += (double)q.part[k * nb + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    tot[k] = red[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n = 4.0 * q.B * (double)q.Z * q.Y * q.X;
+    const float mse = (float)(tot[0] / n);
+    const float sumM = (float)tot[3];
+    const float grd = q.w_g != 0.f ? (float)tot[1] / (4.f * sumM + 1.f) : 0.f;
+    const float div = q.w_d != 0.f ? (float)tot[2] / (sumM + 1.f) : 0.f;
+    q.terms[0] = mse, q.terms[1] = grd, q.terms[2] = div;
+    q.terms[3] = mse + q.w_g * grd + q.w_d * div;
+    q.sums[0] = (float)tot[0], q.sums[1] = (float)tot[1], q.sums[2] = (float)tot[2], q.sums[3] = sumM;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mix_pass2_kernel(const MixParams q) {
+  const long long zyx = (long long)q.Z * q.Y * q.X;
+  const long long total = (long long)q.B * zyx;
+  const long long sy = q.X, sz = (long long)q.Y * q.X;
+  const float sumM = q.sums[3];
+  const float c_mse = 2.f / (4.f * (float)q.B * (float)zyx);
+  const float c_grd = q.w_g != 0.f ? q.w_g / (4.f * sumM + 1.f) : 0.f;
+  const float w5 = 1.f / (2.f * q.delta);
+  const float k = q.delta / q.mean_scale;
+  const float c_div = q.w_d != 0.f ? q.w_d / (sumM + 1.f) * (-2.f * k * w5) : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int x = (int)(r % q.X);
+    r /= q.X;
+    const int y = (int)(r % q.Y);
+    r /= q.Y;
+    const int z = (int)(r % q.Z);
+    const int b = (int)(r / q.Z);
+    const long long sp = i - (long long)b * zyx;
+    const float* P = q.p + (long long)b * 4 * zyx + sp;
+    const float* T = q.t + (long long)b * 4 * zyx + sp;
+    const float* Mf = q.fieldM + i;
+    const float* Ef = q.fieldE + i;
+    // neighbours o = q -+ e that can carry a stencil (M is zero outside the interior, but the
+    // far point q -+ 2e must exist to recompute the difference)
+    const bool xm = x >= 2, xp = x < q.X - 2, ym = y >= 2, yp = y < q.Y - 2, zm = z >= 2, zp = z < q.Z - 2;
+    const float Mxm = xm ? Mf[-1] : 0.f, Mxp = xp ? Mf[1] : 0.f;
+    const float Mym = ym ? Mf[-sy] : 0.f, Myp = yp ? Mf[sy] : 0.f;
+    const float Mzm = zm ? Mf[-sz] : 0.f, Mzp = zp ? Mf[sz] : 0.f;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float* Pc = P + c * zyx;
+      const float* Tc = T + c * zyx;
+      const float d0 = Pc[0] - Tc[0];
+      float g = c_mse * d0;
+      if (c_grd != 0.f) {
+        float acc = 0.f;
+        if (Mxm != 0.f) acc += Mxm * cdiff(d0, Pc[-2] - Tc[-2], 0.5f);
+        if (Mxp != 0.f) acc -= Mxp * cdiff(Pc[2] - Tc[2], d0, 0.5f);
+        if (Mym != 0.f) acc += Mym * cdiff(d0, Pc[-2 * sy] - Tc[-2 * sy], 0.5f);
+        if (Myp != 0.f) acc -= Myp * cdiff(Pc[2 * sy] - Tc[2 * sy], d0, 0.5f);
+        if (Mzm != 0.f) acc += Mzm * cdiff(d0, Pc[-2 * sz] - Tc[-2 * sz], 0.5f);
+        if (Mzp != 0.f) acc -= Mzp * cdiff(Pc[2 * sz] - Tc[2 * sz], d0, 0.5f);
+        g += c_grd * acc;
+      }
+      out[c] = g;
+    }
+    if (c_div != 0.f) {
+      const float ex = (x >= 1 ? Ef[-1] : 0.f) - (x < q.X - 1 ? Ef[1] : 0.f);
+      const float ey = (y >= 1 ? Ef[-sy] : 0.f) - (y < q.Y - 1 ? Ef[sy] : 0.f);
+      const float ez = (z >= 1 ? Ef[-sz] : 0.f) - (z < q.Z - 1 ? Ef[sz] : 0.f);
+      out[1] += c_div * q.s[0] * ex;
+      out[2] += c_div * q.s[1] * ey;
+      out[3] += c_div * q.s[2] * ez;
+    }
+    float* D = q.dldp + (long long)b * 4 * zyx + sp;
+#pragma unroll
+    for (int c = 0; c < 4; c++) D[c * zyx] = out[c];
+  }
+}
+
+inline int grid_for(long long n, int per_thread) {
+  long long b = (n + (long long)kThreads * per_thread - 1) / ((long long)kThreads * per_thread);
+  return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sr3d_loss_workspace_bytes(int B, int Z, int Y, int X) {
+  const size_t vox = (size_t)B * Z * Y * X;
+  return (2 * vox + 4 * (size_t)kMaxBlocks + 16) * sizeof(float);
+}
+
+int sr3d_l1_fwd_bwd(const void* p, const void* t, long long n, void* loss_out, void* dLdp, void* workspace,
+                    void* stream) {
+  SR3D_CHECK(p && t && loss_out && workspace && n > 0, SR3D_E_ARG, "l1_fwd_bwd: bad argument");
+  SR3D_CHECK(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(dLdp)) &
+              15) == 0,
+             SR3D_E_ARG, "l1_fwd_bwd: pointers must be 16-byte aligned");
+  const int nb = grid_for(n, 8);
+  hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, (const float*)p, (const float*)t, n,
+                     (float*)workspace, (float*)dLdp, (float)(1.0 / (double)n));
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, (const float*)workspace, nb,
+                     (float*)loss_out, 1.0 / (double)n);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, int B, int Z, int Y, int X,
+                                   const float scales[3], float delta_meter, float w_g, float w_d, void* terms_out,
+                                   void* dLdp, void* workspace, void* stream) {
+  SR3D_CHECK(p && t && b && terms_out && workspace && scales, SR3D_E_ARG, "mixed_loss: null pointer");
+  SR3D_CHECK(B > 0 && Z >= 3 && Y >= 3 && X >= 3, SR3D_E_ARG, "mixed_loss: grid must be at least 3^3 (got %d,%d,%d)",
+             Z, Y, X);
+  SR3D_CHECK(delta_meter > 0.f, SR3D_E_ARG, "mixed_loss: delta_meter must be positive");
+  const long long vox = (long long)B * Z * Y * X;
+  MixParams q{};
+  q.p = (const float*)p, q.t = (const float*)t, q.b = (const float*)b;
+  q.B = B, q.Z = Z, q.Y = Y, q.X = X;
+  q.s[0] = scales[0], q.s[1] = scales[1], q.s[2] = scales[2];
+  q.w_g = w_g, q.w_d = w_d, q.delta = delta_meter;
+  // np.mean(scales) in double, then used as a python float against fp32 tensors (loss_maker.py:375,430)
+  q.mean_scale = (float)(((double)scales[0] + (double)scales[1] + (double)scales[2]) / 3.0);
+  float* ws = (float*)workspace;
+  q.fieldM = ws, q.fieldE = ws + vox;
+  q.part = ws + 2 * vox, q.sums = ws + 2 * vox + 4 * kMaxBlocks;
+  q.terms = (float*)terms_out, q.dldp = (float*)dLdp;
+  const int nb = grid_for(vox, 2);
+  hipLaunchKernelGGL(mix_pass1_kernel, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, q);
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(mix_final_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, q, nb);
+  SR3D_HIP(hipGetLastError());
+  if (dLdp) {
+    hipLaunchKernelGGL(mix_pass2_kernel, dim3(grid_for(vox, 1)), dim3(kThreads), 0, (hipStream_t)stream, q);
+    SR3D_HIP(hipGetLastError());
+  }
+  return SR3D_OK;
+}
+
+}  // extern "C"

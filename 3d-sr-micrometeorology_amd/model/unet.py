@@ -1,0 +1,140 @@
+"""UNetSR with the reference's constructor, parameter names and forward
+signature (pytorch/model/unet.py:13-297), running on the fused HIP ops.
+
+Differences in *execution* (not in results):
+ - no ``torch.cat``: every block receives its inputs as a list (virtual concat);
+ - ``nn.Upsample`` + the first concat are one small kernel (``ops.upsample_cat``);
+ - ``UpBlock.up`` (conv + bias + LeakyReLU + VoxelUnshuffle) is one kernel whose
+   epilogue scatters straight into the unshuffled layout."""
+import typing
+from logging import getLogger
+
+import torch
+from torch import nn
+
+from .. import ops
+from .custom_conv import MyConvWithAct2, _as_list
+from .voxel_shuffle import VoxelUnshuffle
+
+logger = getLogger()
+
+
+class DownBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, bias: bool, conv_mode: str, n_layers_in_block: int):
+        super().__init__()
+        assert n_layers_in_block >= 1
+        layers = [MyConvWithAct2(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=bias,
+                                 conv_mode=conv_mode, act=nn.ReLU())]
+        for _ in range(n_layers_in_block - 1):
+            layers.append(MyConvWithAct2(out_channels, out_channels, kernel_size=3, padding=1, bias=bias,
+                                         conv_mode=conv_mode, act=nn.ReLU()))
+        self.convs = nn.Sequential(*layers)
+
+    def forward(self, x) -> torch.Tensor:
+        y = x
+        for layer in self.convs:
+            y = layer(y)
+        return y
+
+
+class UpBlock(nn.Module):
+    def __init__(self, in1_channels: int, in2_channels: int, out_channels: int, bias: bool, conv_mode: str,
+                 n_layers_in_block: int):
+        super().__init__()
+        assert n_layers_in_block >= 1
+        layers = [MyConvWithAct2(in1_channels + in2_channels, out_channels, kernel_size=3, padding=1, bias=bias,
+                                 conv_mode=conv_mode, act=nn.LeakyReLU())]
+        for _ in range(n_layers_in_block - 1):
+            layers.append(MyConvWithAct2(out_channels, out_channels, kernel_size=3, padding=1, bias=bias,
+                                         conv_mode=conv_mode, act=nn.LeakyReLU()))
+        self.convs = nn.Sequential(*layers)
+        # parameter container + markers; executed as ONE fused kernel in forward()
+        self.up = nn.Sequential(nn.Conv3d(in1_channels, in1_channels * 8, kernel_size=3, padding=1), nn.LeakyReLU(),
+                                VoxelUnshuffle(factor=2))
+
+    def forward(self, x1, x2) -> torch.Tensor:
+        x3 = ops.conv3d_act(_as_list(x1), self.up[0].weight, self.up[0].bias, act="lrelu", stride=1, unshuffle=True)
+        y = _as_list(x2) + [x3]
+        for layer in self.convs:
+            y = layer(y)
+        return y
+
+
+class UNetSR(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, num_feat0: int, num_feat1: int, num_feat2: int,
+                 num_feat3: int, num_feat4: int, num_x2upsample: int, num_latent_layers: int,
+                 bias_feat_extraction: bool, conv_mode_feat_extraction: str, conv_mode_down_block: str,
+                 conv_mode_up_block: str, n_layers_in_block: int, **kwargs):
+        super().__init__()
+        logger.info(f"conv_mode_feat_extraction = {conv_mode_feat_extraction}")
+        logger.info(f"conv_mode_down_block = {conv_mode_down_block}")
+        logger.info(f"conv_mode_up_block = {conv_mode_up_block}")
+
+        self.scale = 2 ** num_x2upsample
+        self.up0 = nn.Upsample(scale_factor=self.scale, mode="nearest")  # marker; fused into ops.upsample_cat
+        self.conv0 = MyConvWithAct2(in_channels + 1, num_feat0, kernel_size=3, padding=1, bias=bias_feat_extraction,
+                                    conv_mode=conv_mode_feat_extraction, act=None)
+        self.down = nn.AvgPool3d(kernel_size=2, stride=2)  # marker; executed by ops.avgpool2
+
+        def down_block(cin, cout):
+            return DownBlock(in_channels=cin + 1, out_channels=cout, bias=False, conv_mode=conv_mode_down_block,
+                             n_layers_in_block=n_layers_in_block)
+
+        self.down1 = down_block(num_feat0, num_feat1)
+        self.down2 = down_block(num_feat1, num_feat2)
+        self.down3 = down_block(num_feat2, num_feat3)
+        self.down4 = None
+        has4 = num_feat4 is not None and num_feat4 > 0
+        if has4:
+            self.down4 = down_block(num_feat3, num_feat4)
+
+        latent_layers = []
+        for i in range(num_latent_layers):
+            _in = num_feat3 if i > 0 else num_feat3 + 1
+            latent_layers.append(nn.Conv3d(_in, num_feat3, kernel_size=3, padding=1, bias=False))
+            latent_layers.append(nn.LeakyReLU())
+        self.latent_layers = nn.Sequential(*latent_layers)
+
+        def up_block(c1, c2, cout):
+            return UpBlock(in1_channels=c1 + 1, in2_channels=c2 + 1, out_channels=cout, bias=False,
+                           conv_mode=conv_mode_up_block, n_layers_in_block=n_layers_in_block)
+
+        self.up4 = up_block(num_feat4, num_feat3, num_feat3) if has4 else None
+        self.up3 = up_block(num_feat3, num_feat2, num_feat2)
+        self.up2 = up_block(num_feat2, num_feat1, num_feat1)
+        self.up1 = up_block(num_feat1, num_feat0, num_feat0)
+        self.last = nn.Conv3d(num_feat0 + in_channels + 1, out_channels, kernel_size=3, padding=1, bias=True)
+
+    def get_last_params(self) -> typing.List[torch.nn.Parameter]:
+        return list(self.last.parameters())
+
+    def _latent(self, srcs) -> torch.Tensor:
+        y = srcs
+        for layer in self.latent_layers:
+            if isinstance(layer, nn.Conv3d):
+                y = ops.conv3d_act(_as_list(y), layer.weight, layer.bias, act="lrelu", stride=1)
+        return y
+
+    def forward(self, x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        x0 = ops.upsample_cat(x, b, self.scale)  # cat[up0(x), b]; inputs carry no gradient
+        b = b.detach().contiguous()
+        f0 = self.conv0([x0])
+        b1 = ops.avgpool2(b)
+        f1 = self.down1([f0, b])
+        b2 = ops.avgpool2(b1)
+        f2 = self.down2([f1, b1])
+        b3 = ops.avgpool2(b2)
+        f3 = self.down3([f2, b2])
+
+        if self.down4 is None and self.up4 is None:
+            y = self._latent([f3, b3])
+        else:
+            b4 = ops.avgpool2(b3)
+            f4 = self.down4([f3, b3])
+            y = self._latent([f4, b4])
+            y = self.up4([y, b4], [f3, b3])
+        y = self.up3([y, b3], [f2, b2])
+        y = self.up2([y, b2], [f1, b1])
+        y = self.up1([y, b1], [f0, b])
+        w, bias = self.last.weight, self.last.bias
+        return ops.conv3d_act([y, x0], w, bias, act=None, stride=1)

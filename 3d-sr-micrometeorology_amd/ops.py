@@ -1,0 +1,292 @@
+"""torch.autograd.Functions over the libsr3d C ABI (host side of the hot path).
+
+PyTorch owns every tensor; the library only sees raw device pointers and the
+current HIP stream.  Each Function is one fused HIP forward and its hand-written
+backward -- nothing here falls back to ATen convolution.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _out_dim(z: int, s: int) -> int:
+    return (z - 1) // s + 1
+
+
+def _empty(shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _check_srcs(srcs: Sequence[torch.Tensor]):
+    if not 1 <= len(srcs) <= 4:
+        raise ValueError("a conv input is a concat of 1..4 tensors")
+    s0 = srcs[0]
+    if s0.dim() != 5:
+        raise ValueError("expected (B, C, z, y, x) tensors")
+    for s in srcs[1:]:
+        if s.shape[0] != s0.shape[0] or s.shape[2:] != s0.shape[2:]:
+            raise ValueError(f"concat operands disagree: {tuple(s.shape)} vs {tuple(s0.shape)}")
+    return s0.shape[0], sum(int(s.shape[1]) for s in srcs), tuple(s0.shape[2:])
+
+
+def pack_weights(desc: L.ConvDesc, kind: int, w_feat: torch.Tensor, w_gate: Optional[torch.Tensor]) -> torch.Tensor:
+    nbytes = L.lib.sr3d_packed_weight_bytes(C.byref(desc), kind)
+    if nbytes == 0:
+        raise RuntimeError("sr3d_packed_weight_bytes: " + L.lib.sr3d_last_error().decode())
+    wp = torch.empty(nbytes // 4, dtype=torch.float32, device=w_feat.device)
+    L.check(L.lib.sr3d_pack_weights(C.byref(desc), kind, L.dev_ptr(w_feat, "weight"), L.dev_ptr(w_gate, "gate weight"),
+                                    L.dev_ptr(wp), L.stream_ptr()), "sr3d_pack_weights")
+    return wp
+
+
+def _bias_grad(dpre: torch.Tensor) -> torch.Tensor:
+    B, Cc = dpre.shape[0], dpre.shape[1]
+    vox = dpre[0, 0].numel()
+    ws = torch.empty(max(1, L.lib.sr3d_bias_grad_workspace_bytes(B, Cc, vox) // 4), dtype=torch.float32,
+                     device=dpre.device)
+    db = _empty((Cc,), dpre)
+    L.check(L.lib.sr3d_bias_grad(L.dev_ptr(dpre), B, Cc, vox, L.dev_ptr(db), L.dev_ptr(ws), L.stream_ptr()),
+            "sr3d_bias_grad")
+    return db
+
+
+def _bwd_weight(desc: L.ConvDesc, srcs, dys) -> torch.Tensor:
+    n_total = sum(int(d.shape[1]) for d in dys)
+    nbytes = L.lib.sr3d_conv3d_bwd_weight_workspace_bytes(C.byref(desc), n_total)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dys[0].device)
+    dw = _empty((n_total, desc.Cin, 3, 3, 3), dys[0])
+    L.check(L.lib.sr3d_conv3d_bwd_weight(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.slices(dys, "dy_srcs"),
+                                         len(dys), L.dev_ptr(dw), L.dev_ptr(ws), nbytes, L.stream_ptr()),
+            "sr3d_conv3d_bwd_weight")
+    return dw
+
+
+def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate) -> List[Optional[torch.Tensor]]:
+    if not any(needs):
+        return [None] * len(srcs)
+    kind = L.PACK_BWD_GATED if w_gate is not None else L.PACK_BWD
+    wp = pack_weights(desc, kind, w_feat, w_gate)
+    outs: List[Optional[torch.Tensor]] = [torch.empty_like(s) if n else None for s, n in zip(srcs, needs)]
+    dsts = [o if o is not None else (int(s.shape[1]), None) for o, s in zip(outs, srcs)]
+    L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs"), len(dys), L.dev_ptr(wp),
+                                       L.slices(dsts, "dx_dsts"), len(dsts), L.stream_ptr()), "sr3d_conv3d_bwd_data")
+    return outs
+
+
+class Conv3dAct(torch.autograd.Function):
+    """y = act(conv3d(cat(srcs); W) + bias) [-> unshuffle_voxels(., 2)]
+
+    Stands in for nn.Conv3d (+ nn.LeakyReLU) (+ VoxelUnshuffle) of the reference:
+    pytorch/model/unet.py:99-108 (UpBlock.up), :72-97 (UpBlock.convs), :192-199
+    (latent), :240-246 (last); custom_conv.py:111-116."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, act: Optional[str], stride: int, unshuffle: bool, *srcs):
+        srcs = [s.contiguous() for s in srcs]
+        B, cin, (Z, Y, X) = _check_srcs(srcs)
+        cout = int(weight.shape[0])
+        if tuple(weight.shape[1:]) != (cin, 3, 3, 3):
+            raise ValueError(f"weight {tuple(weight.shape)} does not match {cin} input channels / 3x3x3")
+        weight = weight.contiguous()
+        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride)
+        wp = pack_weights(desc, L.PACK_FWD, weight, None)
+        oz, oy, ox = _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride)
+        if unshuffle:
+            y = _empty((B, cout // 8, 2 * oz, 2 * oy, 2 * ox), srcs[0])
+        else:
+            y = _empty((B, cout, oz, oy, ox), srcs[0])
+        L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.dev_ptr(wp),
+                                      L.dev_ptr(bias, "bias"), L.dev_ptr(y), L.ACT_CODE[act], int(bool(unshuffle)),
+                                      L.stream_ptr()), "sr3d_conv3d_fwd")
+        ctx.desc, ctx.act, ctx.unshuffle, ctx.has_bias, ctx.nsrc = desc, act, unshuffle, bias is not None, len(srcs)
+        ctx.save_for_backward(weight, y if act is not None else None, *srcs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, y, *srcs = ctx.saved_tensors
+        desc = ctx.desc
+        dy = dy.contiguous()
+        if ctx.unshuffle:
+            B, c, z2, y2, x2 = dy.shape
+            dpre = _empty((B, 8 * c, z2 // 2, y2 // 2, x2 // 2), dy)
+            if ctx.act != "lrelu":
+                raise NotImplementedError("unshuffle epilogue is defined with LeakyReLU (unet.py:99-108)")
+            L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy), L.dev_ptr(y), L.dev_ptr(dpre), B, c, z2 // 2,
+                                                   y2 // 2, x2 // 2, L.stream_ptr()), "sr3d_unshuffle_lrelu_bwd")
+        elif ctx.act == "lrelu":
+            dpre = torch.empty_like(dy)
+            L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dy), L.dev_ptr(y), L.dev_ptr(dpre), dy.numel(), L.stream_ptr()),
+                    "sr3d_lrelu_bwd")
+        elif ctx.act is None:
+            dpre = dy
+        else:
+            raise NotImplementedError(f"backward of plain conv with act={ctx.act}")
+        needs = ctx.needs_input_grad[5:5 + ctx.nsrc]
+        dxs = _bwd_data(desc, srcs, needs, [dpre], weight, None)
+        dw = _bwd_weight(desc, srcs, [dpre]) if ctx.needs_input_grad[0] else None
+        db = _bias_grad(dpre) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return (dw, db, None, None, None, *dxs)
+
+
+class GatedConv3dAct(torch.autograd.Function):
+    """y = sigmoid(conv(x; Wg) + bg) * act(conv(x; Wf) [+ bf])
+
+    One fused kernel for ``GatedConv3d(WithSeparatedBias)`` + ``MyConvWithAct2``
+    (reference custom_conv.py:119-123, 237-306)."""
+
+    @staticmethod
+    def forward(ctx, w_feat, w_gate, b_feat, b_gate, act: Optional[str], stride: int, *srcs):
+        srcs = [s.contiguous() for s in srcs]
+        B, cin, (Z, Y, X) = _check_srcs(srcs)
+        cout = int(w_feat.shape[0])
+        if tuple(w_feat.shape) != (cout, cin, 3, 3, 3) or w_gate.shape != w_feat.shape:
+            raise ValueError("gated conv: weight shapes do not match the input")
+        w_feat, w_gate = w_feat.contiguous(), w_gate.contiguous()
+        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride)
+        wp = pack_weights(desc, L.PACK_FWD_GATED, w_feat, w_gate)
+        oshape = (B, cout, _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride))
+        y = _empty(oshape, srcs[0])
+        need_bwd = any(ctx.needs_input_grad)
+        sf = _empty(oshape, y) if need_bwd else None
+        ss = _empty(oshape, y) if need_bwd else None
+        L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.dev_ptr(wp),
+                                            L.dev_ptr(b_feat, "feature bias"), L.dev_ptr(b_gate, "gate bias"),
+                                            L.dev_ptr(y), L.dev_ptr(sf), L.dev_ptr(ss), L.ACT_CODE[act],
+                                            L.stream_ptr()), "sr3d_gated_conv3d_fwd")
+        ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
+        ctx.save_for_backward(w_feat, w_gate, sf, ss, *srcs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w_feat, w_gate, sf, ss, *srcs = ctx.saved_tensors
+        desc = ctx.desc
+        dy = dy.contiguous()
+        d_feat, d_gate = torch.empty_like(dy), torch.empty_like(dy)
+        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy), L.dev_ptr(sf), L.dev_ptr(ss), L.dev_ptr(d_feat),
+                                         L.dev_ptr(d_gate), dy.numel(), L.ACT_CODE[ctx.act], L.stream_ptr()),
+                "sr3d_gated_act_bwd")
+        needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
+        dxs = _bwd_data(desc, srcs, needs, [d_feat, d_gate], w_feat, w_gate)
+        dwf = dwg = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dw = _bwd_weight(desc, srcs, [d_feat, d_gate])
+            dwf, dwg = dw[:desc.Cout], dw[desc.Cout:]
+        dbf = _bias_grad(d_feat) if (ctx.has_bf and ctx.needs_input_grad[2]) else None
+        dbg = _bias_grad(d_gate) if ctx.needs_input_grad[3] else None
+        return (dwf, dwg, dbf, dbg, None, None, *dxs)
+
+
+def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False):
+    return Conv3dAct.apply(weight, bias, act, stride, unshuffle, *srcs)
+
+
+def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):
+    return GatedConv3dAct.apply(w_feat, w_gate, b_feat, b_gate, act, stride, *srcs)
+
+
+# ---------------------------------------------------------------- no-grad data movement
+def upsample_cat(x: torch.Tensor, b: torch.Tensor, scale: int) -> torch.Tensor:
+    """cat[nearest_upsample(x, scale), b]  (reference unet.py:143,254-255); inputs carry no gradient."""
+    x, b = x.detach().contiguous(), b.detach().contiguous()
+    B, c = x.shape[0], x.shape[1]
+    Z, Y, X = b.shape[2:]
+    if tuple(x.shape[2:]) != (Z // scale, Y // scale, X // scale) or b.shape[1] != 1 or b.shape[0] != B:
+        raise ValueError(f"upsample_cat: x {tuple(x.shape)} x{scale} does not match mask {tuple(b.shape)}")
+    out = _empty((B, c + 1, Z, Y, X), x)
+    L.check(L.lib.sr3d_upsample_cat(L.dev_ptr(x), L.dev_ptr(b), L.dev_ptr(out), B, c, Z, Y, X, scale, L.stream_ptr()),
+            "sr3d_upsample_cat")
+    return out
+
+
+def avgpool2(b: torch.Tensor) -> torch.Tensor:
+    """nn.AvgPool3d(2, 2) of the (B,1,Z,Y,X) building mask (reference unet.py:156)."""
+    b = b.detach().contiguous()
+    B, c, Z, Y, X = b.shape
+    if c != 1:
+        raise ValueError("avgpool2 is the mask pyramid op: one channel")
+    out = _empty((B, 1, Z // 2, Y // 2, X // 2), b)
+    L.check(L.lib.sr3d_avgpool2(L.dev_ptr(b), L.dev_ptr(out), B, Z, Y, X, L.stream_ptr()), "sr3d_avgpool2")
+    return out
+
+
+def near_wall_mask(b: torch.Tensor) -> torch.Tensor:
+    """calc_mask_near_build_wall (reference loss_maker.py:57-83)."""
+    b = b.detach().contiguous()
+    B, c, Z, Y, X = b.shape
+    if c != 1:
+        raise ValueError("near_wall_mask expects a (B,1,Z,Y,X) mask")
+    out = torch.empty_like(b)
+    L.check(L.lib.sr3d_near_wall(L.dev_ptr(b), L.dev_ptr(out), B, Z, Y, X, L.stream_ptr()), "sr3d_near_wall")
+    return out
+
+
+# ---------------------------------------------------------------- losses
+class L1LossFn(torch.autograd.Function):
+    """mean |p - t| and its gradient in one pass (reference loss_maker.py:194-202)."""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = p.contiguous(), t.detach().contiguous()
+        if p.shape != t.shape:
+            raise ValueError("L1: shapes differ")
+        need = ctx.needs_input_grad[0]
+        ws = torch.empty(L.lib.sr3d_loss_workspace_bytes(1, 1, 1, 1) // 4, dtype=torch.float32, device=p.device)
+        out = _empty((1,), p)
+        g = torch.empty_like(p) if need else None
+        L.check(L.lib.sr3d_l1_fwd_bwd(L.dev_ptr(p), L.dev_ptr(t), p.numel(), L.dev_ptr(out), L.dev_ptr(g),
+                                      L.dev_ptr(ws), L.stream_ptr()), "sr3d_l1_fwd_bwd")
+        ctx.save_for_backward(g)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None
+
+
+class MixedLossFn(torch.autograd.Function):
+    """MixedDivergenceGradientL2Loss terms + dL/dp (reference loss_maker.py:387-450).
+    Returns a 4-vector (mse, grd_mse, div_mse, total); only ``total`` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, p, t, b, scales, delta, w_g, w_d):
+        p, t, b = p.contiguous(), t.detach().contiguous(), b.detach().contiguous()
+        B, c, Z, Y, X = p.shape
+        if c != 4 or t.shape != p.shape or tuple(b.shape) != (B, 1, Z, Y, X):
+            raise ValueError("mixed loss expects p,t: (B,4,Z,Y,X) and masks: (B,1,Z,Y,X)")
+        need = ctx.needs_input_grad[0]
+        ws = torch.empty(L.lib.sr3d_loss_workspace_bytes(B, Z, Y, X) // 4, dtype=torch.float32, device=p.device)
+        terms = _empty((4,), p)
+        g = torch.empty_like(p) if need else None
+        sc = (C.c_float * 3)(*[float(s) for s in scales])
+        L.check(L.lib.sr3d_mixed_div_grad_l2_fwd_bwd(L.dev_ptr(p), L.dev_ptr(t), L.dev_ptr(b), B, Z, Y, X, sc,
+                                                     float(delta), float(w_g), float(w_d), L.dev_ptr(terms),
+                                                     L.dev_ptr(g), L.dev_ptr(ws), L.stream_ptr()),
+                "sr3d_mixed_div_grad_l2_fwd_bwd")
+        ctx.save_for_backward(g)
+        return terms
+
+    @staticmethod
+    def backward(ctx, gterms):
+        (g,) = ctx.saved_tensors
+        # d(total)/dp is what the kernel produced; the three individual terms are reported without gradient
+        return g * gterms[3], None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------- optimizer
+def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float,
+               beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0) -> None:
+    """in-place fused Adam on flat fp32 buffers (torch.optim.Adam defaults; reference train_model.py:183)."""
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+        raise ValueError("adam_step_: buffer sizes differ")
+    L.check(L.lib.sr3d_adam_step(L.dev_ptr(param), L.dev_ptr(grad), L.dev_ptr(exp_avg), L.dev_ptr(exp_avg_sq), n,
+                                 float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                                 L.stream_ptr()), "sr3d_adam_step")

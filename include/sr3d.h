@@ -1,0 +1,146 @@
+/* libsr3d -- C ABI of the MI355X-native voxel super-resolution training hot path.
+ *
+ * The reference (YukiYasuda2718/3d-sr-micrometeorology) has no FFI of its own:
+ * every operation on its hot path is a call into PyTorch/ATen (SURVEY.md section
+ * 2b, 8b).  Each entry point below replaces one such call site; the reference
+ * line it stands in for is cited next to it.  A Python/ctypes binding is in
+ * 3d-sr-micrometeorology_amd/_lib.py; INTEGRATION.md shows how the reference's
+ * modules would call it.
+ *
+ * Conventions
+ *  - all tensors are dense fp32, layout NCDHW = (B, C, z, y, x), x contiguous;
+ *  - every pointer is a DEVICE pointer unless stated; the library never
+ *    allocates, frees or caches device memory -- workspaces are passed in and
+ *    sized by the *_bytes() queries;
+ *  - every call is asynchronous on the hipStream_t handed in (passed as void*)
+ *    and re-entrant (autograd calls backward from another thread);
+ *  - return value 0 = ok, negative = SR3D_E_*; sr3d_last_error() gives the
+ *    message of the calling thread's last failure.  Nothing throws.
+ */
+#ifndef SR3D_H_
+#define SR3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR3D_VERSION 100 /* 0.1.0 */
+
+enum {
+  SR3D_OK = 0,
+  SR3D_E_ARG = -1,     /* bad argument / unsupported shape */
+  SR3D_E_HIP = -2,     /* a HIP runtime call failed */
+  SR3D_E_WORKSPACE = -3 /* workspace too small */
+};
+
+/* activations fused into conv epilogues (custom_conv.py:111-126, unet.py:35,84,105) */
+enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */ };
+
+/* One operand of a virtual channel concatenation (replaces torch.cat at
+ * unet.py:255-293): `channels` channels of a (B, channels, Z, Y, X) tensor.
+ * As a gradient destination ptr may be NULL (that slice needs no gradient). */
+typedef struct {
+  void* ptr;
+  int32_t channels;
+} sr3d_slice_t;
+
+/* 3x3x3 convolution, padding 1 (every nn.Conv3d of the model: unet.py:30,44,76,
+ * 89,103,196,243).  (Z,Y,X) is the INPUT grid; the output grid is
+ * floor((Z-1)/stride)+1 per dim.  For gated layers Cout is the width of ONE
+ * branch. */
+typedef struct {
+  int32_t B, Cin, Cout;
+  int32_t Z, Y, X;
+  int32_t stride; /* 1 or 2 */
+} sr3d_conv_desc_t;
+
+/* kinds of packed (MFMA-tile-ordered) weight images */
+enum {
+  SR3D_PACK_FWD = 0,        /* plain conv forward                              */
+  SR3D_PACK_FWD_GATED = 1,  /* feature + gate branches interleaved by 32 rows  */
+  SR3D_PACK_BWD = 2,        /* transposed image for bwd_data                   */
+  SR3D_PACK_BWD_GATED = 3   /* K = [d_feat ; d_gate]                           */
+};
+
+int sr3d_version(void);
+const char* sr3d_last_error(void);
+
+/* ---- weights ------------------------------------------------------------ */
+/* bytes of the packed image of one layer */
+size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind);
+/* w_feat / w_gate: (Cout, Cin, 3,3,3) as in the state_dict; w_gate only for *_GATED */
+int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, const void* w_gate,
+                      void* w_packed, void* stream);
+
+/* ---- forward ------------------------------------------------------------ */
+/* y = act(conv3d(cat(x_srcs); W) + bias)           nn.Conv3d + LeakyReLU: unet.py:196-198, 72-97, 240-246
+ * unshuffle != 0: y is written as unshuffle_voxels(., 2) of that (voxel_shuffle.py:26-42, unet.py:99-108),
+ *                 i.e. y has Cout/8 channels on the 2x grid. */
+int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
+                    const void* bias, void* y, int act, int unshuffle, void* stream);
+
+/* y = sigmoid(conv(x;Wg)+bg) * act(conv(x;Wf)[+bf])   custom_conv.py:119-123, 303-304
+ * save_f = act(feat), save_s = sigmoid(gate) are kept for the backward pass. */
+int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
+                          const void* bias_f, const void* bias_g, void* y, void* save_f, void* save_s, int act,
+                          void* stream);
+
+/* ---- backward (autograd of the above: optim_helper.py:165 loss.backward()) -- */
+/* dx_dsts[i] = slice i of d(cat(x))/ = conv_transpose(cat(dy_srcs); W)  (aten convolution_backward, input grad)
+ * dy_srcs hold the gradient w.r.t. the PRE-activation conv outputs (1 slice, or 2 = [d_feat, d_gate]). */
+int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_packed_bwd,
+                         const sr3d_slice_t* dx_dsts, int n_dst, void* stream);
+
+/* dw[(n, c, kz,ky,kx)] over n in cat(dy_srcs) channels (so for gated layers dw = [dWf ; dWg]).
+ * deterministic: fixed split of the voxel reduction + ordered second stage. */
+size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total);
+int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src,
+                           const sr3d_slice_t* dy_srcs, int n_dy, void* dw, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* db[c] = sum_{b,voxels} dy[b,c,:]   (bias gradient); workspace >= sr3d_bias_grad_workspace_bytes */
+size_t sr3d_bias_grad_workspace_bytes(int B, int C, long long voxels);
+int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, void* stream);
+
+/* d_feat = dy * s * act'(f),  d_gate = dy * f * s * (1 - s)      (autograd of custom_conv.py:119-123) */
+int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
+                       long long n, int act, void* stream);
+/* dpre = dy * (y > 0 ? 1 : 0.01)        (autograd of nn.LeakyReLU, y = post-activation) */
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, void* stream);
+/* dpre(B, 8C, Z, Y, X) = shuffle_voxels(dy * lrelu'(y)) for y, dy of shape (B, C, 2Z, 2Y, 2X)
+ * (autograd of unet.py:99-108 up to the conv) */
+int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X,
+                             void* stream);
+
+/* ---- small data-movement ops ------------------------------------------------ */
+/* x0 = cat[nearest_upsample(x, scale), b]     unet.py:143,254-255 ; x: (B,C,Z/s,Y/s,X/s), b: (B,1,Z,Y,X) */
+int sr3d_upsample_cat(const void* x, const void* b, void* x0, int B, int C, int Z, int Y, int X, int scale,
+                      void* stream);
+/* out = AvgPool3d(2,2)(in) for a (B,1,Z,Y,X) mask          unet.py:156,261 */
+int sr3d_avgpool2(const void* in, void* out, int B, int Z, int Y, int X, void* stream);
+/* near = calc_mask_near_build_wall(b)                       loss_maker.py:57-83 */
+int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* stream);
+
+/* ---- losses (forward value + dL/dp in one pass) --------------------------- */
+/* out[0] = mean|p-t| ; dLdp = sign(p-t)/n * grad_scale           MyL1Loss, loss_maker.py:194-202 */
+size_t sr3d_loss_workspace_bytes(int B, int Z, int Y, int X);
+int sr3d_l1_fwd_bwd(const void* p, const void* t, long long n, void* loss_out, void* dLdp, void* workspace,
+                    void* stream);
+/* MixedDivergenceGradientL2Loss, loss_maker.py:358-450.  p,t: (B,4,Z,Y,X); b: (B,1,Z,Y,X).
+ * terms_out (device, 4 floats) = {mse, grd_mse, div_mse, total};  dLdp may be NULL. */
+int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, int B, int Z, int Y, int X,
+                                   const float scales[3], float delta_meter, float w_g, float w_d,
+                                   void* terms_out, void* dLdp, void* workspace, void* stream);
+
+/* ---- optimizer -------------------------------------------------------------- */
+/* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based. */
+int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR3D_H_ */

@@ -1,0 +1,242 @@
+"""HIP path vs golden vectors / CPU oracle -- run on the MI355X box (pytest -m gpu).
+
+Tolerances are NORMWISE relative errors ||a-b||/||b||:
+1e-5 for activations/predictions/losses as BASELINE.json's north_star states;
+parameter gradients get 5e-5 because the reference's own fp32-vs-fp64 noise on
+them is already up to 5e-6."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, cfg_of, load_golden, relerr, sub
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+TOL_G = 5e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sr3d_amd
+    return sr3d_amd
+
+
+@pytest.fixture(scope="module")
+def ops_g():
+    return load_golden("ops.npz")
+
+
+DEV = "cuda:0"
+
+CONV_CASES = ["gated_s1_none", "gated_s2_relu", "gated_s1_relu_bias", "gconv_s1_relu", "plain_s1_lrelu",
+              "plain_s1_bias_none", "plain_s2_lrelu", "wide_s1_lrelu", "wide_gated_s2_relu"]
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+def test_conv_wrappers_vs_golden(eng, ops_g, name):
+    from torch import nn
+    meta = json.loads(str(ops_g[f"conv/{name}/meta"]))
+    act = {None: None, "relu": nn.ReLU(), "lrelu": nn.LeakyReLU()}[meta["act"]]
+    mod = eng.model.custom_conv.MyConvWithAct2(meta["cin"], meta["cout"], 3, stride=meta["stride"], padding=1,
+                                               bias=meta["bias"], conv_mode=meta["mode"], act=act)
+    mod.load_state_dict(sub(ops_g, f"conv/{name}/sd"))
+    mod.to(DEV)
+    x = T(ops_g[f"conv/{name}/x"]).to(DEV).requires_grad_(True)
+    y = mod(x)
+    assert relerr(y, ops_g[f"conv/{name}/y"]) < TOL
+    y.backward(T(ops_g[f"conv/{name}/gy"]).to(DEV))
+    assert relerr(x.grad, ops_g[f"conv/{name}/gx"]) < TOL
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad, ops_g[f"conv/{name}/grad/{k}"]) < TOL_G, k
+
+
+def test_split_sources_equal_concat(eng, ops_g):
+    """a virtual concat of 3 tensors must equal the conv of the materialised concat"""
+    name = "wide_s1_lrelu"
+    w = T(ops_g[f"conv/{name}/sd/conv.weight"]).to(DEV).requires_grad_(True)
+    x = T(ops_g[f"conv/{name}/x"]).to(DEV)
+    parts = [x[:, :33].contiguous().requires_grad_(True), x[:, 33:34].contiguous(),
+             x[:, 34:].contiguous().requires_grad_(True)]
+    y = eng.ops.conv3d_act(parts, w, None, act="lrelu")
+    assert relerr(y, ops_g[f"conv/{name}/y"]) < TOL
+    y.backward(T(ops_g[f"conv/{name}/gy"]).to(DEV))
+    gx = T(ops_g[f"conv/{name}/gx"])
+    assert relerr(parts[0].grad, gx[:, :33]) < TOL
+    assert parts[1].grad is None
+    assert relerr(parts[2].grad, gx[:, 34:]) < TOL
+    assert relerr(w.grad, ops_g[f"conv/{name}/grad/conv.weight"]) < TOL_G
+
+
+def test_upblock_vs_golden(eng, ops_g):
+    ub = eng.model.unet.UpBlock(in1_channels=9, in2_channels=5, out_channels=4, bias=False, conv_mode=None,
+                                n_layers_in_block=2)
+    ub.load_state_dict(sub(ops_g, "upblock/sd"))
+    ub.to(DEV)
+    x1 = T(ops_g["upblock/x1"]).to(DEV).requires_grad_(True)
+    x2 = T(ops_g["upblock/x2"]).to(DEV).requires_grad_(True)
+    x3 = eng.ops.conv3d_act([x1], ub.up[0].weight, ub.up[0].bias, act="lrelu", unshuffle=True)
+    assert relerr(x3, ops_g["upblock/x3"]) < TOL
+    y = ub(x1, x2)
+    assert relerr(y, ops_g["upblock/y"]) < TOL
+    y.backward(T(ops_g["upblock/gy"]).to(DEV))
+    assert relerr(x1.grad, ops_g["upblock/gx1"]) < TOL
+    assert relerr(x2.grad, ops_g["upblock/gx2"]) < TOL
+    for k, p in ub.named_parameters():
+        assert relerr(p.grad, ops_g[f"upblock/grad/{k}"]) < TOL_G, k
+
+
+def test_mask_ops_bit_exact(eng, ops_g):
+    for tag in ("iid", "tower"):
+        b = T(ops_g[f"wall/b_{tag}"]).to(DEV)
+        assert torch.equal(eng.ops.near_wall_mask(b).cpu(), T(ops_g[f"wall/near_{tag}"]))
+    cur = T(ops_g["wall/b_tower"]).to(DEV)
+    for lvl in range(1, 5):
+        cur = eng.ops.avgpool2(cur)
+        assert torch.equal(cur.cpu(), T(ops_g[f"pool/tower_l{lvl}"]))
+
+
+def test_upsample_cat_bit_exact(eng):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 4, 3, 5, 6, generator=g)
+    b = (torch.rand(2, 1, 12, 20, 24, generator=g) > 0.2).float()
+    out = eng.ops.upsample_cat(x.to(DEV), b.to(DEV), 4).cpu()
+    ref = torch.cat([x.repeat_interleave(4, 2).repeat_interleave(4, 3).repeat_interleave(4, 4), b], 1)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("fname", ["model_tiny_a.npz", "model_tiny_b.npz"])
+def test_losses_vs_golden(eng, fname):
+    d = load_golden(fname)
+    cfg = cfg_of(d)
+    p0, y, b = T(d["pred"]).to(DEV), T(d["y"]).to(DEV), T(d["b"]).to(DEV)
+    for tag, (wg, wd) in {"g1d10": (1.0, 10.0), "g0d0": (0.0, 0.0), "g1d0": (1.0, 0.0), "g0d10": (0.0, 10.0)}.items():
+        c2 = json.loads(json.dumps(cfg))
+        c2["train"]["loss"]["weight_gradient_loss"] = wg
+        c2["train"]["loss"]["weight_divergence_loss"] = wd
+        lf = eng.make_loss(c2)
+        p = p0.clone().requires_grad_(True)
+        terms = lf.calc_loss_terms(predicts=p, targets=y, masks=b)
+        for a, r in zip(terms, d[f"loss/{tag}/terms"]):
+            assert abs(float(a) - float(r)) <= TOL * max(abs(float(r)), 1e-30), (tag, float(a), float(r))
+        tot = lf(p, y, b)
+        tot.backward()
+        assert abs(float(tot) - float(d[f"loss/{tag}/total"])) < TOL * float(d[f"loss/{tag}/total"])
+        assert relerr(p.grad, d[f"loss/{tag}/dpred"]) < TOL, tag
+    c2 = json.loads(json.dumps(cfg))
+    c2["train"]["loss"] = {"name": "L1"}
+    p = p0.clone().requires_grad_(True)
+    l1 = eng.make_loss(c2)(p, y, b)
+    l1.backward()
+    assert abs(float(l1) - float(d["loss/l1/total"])) < TOL * float(d["loss/l1/total"])
+    assert relerr(p.grad, d["loss/l1/dpred"]) < TOL
+
+
+@pytest.mark.parametrize("fname", ["model_tiny_a.npz", "model_tiny_b.npz"])
+def test_full_model_forward_backward_vs_golden(eng, fname):
+    d = load_golden(fname)
+    cfg = cfg_of(d)
+    model = eng.make_model(cfg)
+    model.load_state_dict(sub(d, "sd"))
+    model.to(DEV)
+    x, b, y = T(d["x"]).to(DEV), T(d["b"]).to(DEV), T(d["y"]).to(DEV)
+    pred = model(x, b)
+    assert relerr(pred, d["pred"]) < TOL
+    assert relerr(pred, d["f64/pred"]) < TOL
+    loss = eng.make_loss(cfg)(pred, y, b)
+    assert abs(float(loss) - float(d["train_loss"])) < TOL * float(d["train_loss"])
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        e = min(relerr(p.grad, d["grad/" + k]), relerr(p.grad, d["f64/grad/" + k]))
+        worst = max(worst, e)
+        assert e < TOL_G, (k, e)
+    print(f"{fname}: worst parameter-gradient error {worst:.2e}")
+
+
+def test_two_adam_steps_vs_golden(eng):
+    d = load_golden("train2.npz")
+    cfg = cfg_of(d)
+    model = eng.make_model(cfg)
+    model.load_state_dict(sub(d, "sd0"))
+    model.to(DEV)
+    loss_fn = eng.make_loss(cfg)
+    opt = eng.FlatAdam(model.parameters(), lr=float(d["lr"]))
+    xs, bs, ys = T(d["x"]).to(DEV), T(d["b"]).to(DEV), T(d["y"]).to(DEV)
+    losses = []
+    for i in range(2):
+        pred = model(xs[i:i + 1], bs[i:i + 1].unsqueeze(1))
+        loss = loss_fn(pred, ys[i:i + 1], bs[i:i + 1].unsqueeze(1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert abs(np.mean(losses) - float(d["avg_loss"])) < 1e-5 * float(d["avg_loss"])
+    sd2 = sub(d, "sd2")
+    for k, v in model.state_dict().items():
+        assert relerr(v, sd2[k]) < 1e-5, k
+        upd, ref_upd = v.cpu() - T(d["sd0/" + k]), sd2[k] - T(d["sd0/" + k])
+        assert relerr(upd, ref_upd) < 5e-3, k
+
+
+def test_fullwidth_layers(eng):
+    d = load_golden("fullwidth.npz")
+    for name in ("up1_up0", "up1_convs0"):
+        meta = json.loads(str(d[f"{name}/meta"]))
+        g = torch.Generator().manual_seed(meta["seed"])
+        cin, cout = meta["cin"], meta["cout"]
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        x = torch.rand(1, cin, *meta["grid"], generator=g) - 0.5
+        y = eng.ops.conv3d_act([x.to(DEV)], w.to(DEV), bias.to(DEV), act="lrelu", unshuffle=name.endswith("up0"))
+        assert relerr(y, d[f"{name}/y"]) < TOL
+
+
+@pytest.mark.parametrize("shape,stride,cin,cout", [((5, 7, 9), 2, 6, 5), ((6, 33, 40), 1, 3, 36), ((7, 9, 70), 2, 10, 8),
+                                                   ((3, 3, 3), 1, 1, 1), ((2, 2, 2), 2, 2, 3)])
+def test_odd_shapes_vs_oracle(eng, shape, stride, cin, cout):
+    """ragged / odd / tiny grids: tile-edge masking, stride-2 parity classes with odd extents"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape) + cin)
+    x = (torch.rand(2, cin, *shape, generator=g) - 0.5).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    bias = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    ref = F.leaky_relu(F.conv3d(x, w, bias, stride=stride, padding=1), 0.01)
+    gy = torch.rand(ref.shape, generator=g) - 0.5
+    ref.backward(gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    bd = bias.detach().to(DEV).requires_grad_(True)
+    y = eng.ops.conv3d_act([xd], wd, bd, act="lrelu", stride=stride)
+    assert relerr(y, ref) < TOL
+    y.backward(gy.to(DEV))
+    assert relerr(xd.grad, x.grad) < TOL
+    assert relerr(wd.grad, w.grad) < TOL_G
+    assert relerr(bd.grad, bias.grad) < TOL_G
+
+
+def test_wgrad_is_deterministic(eng):
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 20, 8, 16, 40, generator=g).to(DEV)
+    w = torch.randn(24, 20, 3, 3, 3, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.rand(1, 24, 8, 16, 40, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        w.grad = None
+        eng.ops.conv3d_act([x], w, None, act=None).backward(gy)
+        outs.append(w.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_errors_are_loud(eng):
+    x = torch.rand(1, 3, 4, 4, 4)
+    w = torch.rand(2, 3, 3, 3, 3)
+    with pytest.raises(RuntimeError):
+        eng.ops.conv3d_act([x], w, None)          # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        eng.ops.conv3d_act([x.to(DEV)], torch.rand(2, 4, 3, 3, 3).to(DEV), None)
+    with pytest.raises(NotImplementedError):
+        eng.model.custom_conv.MyConvWithAct2(3, 2, 3, padding=1, conv_mode="p_conv")
