@@ -32,7 +32,60 @@ int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channe
   return SR3D_OK;
 }
 
+// ---- optional per-kernel timing with HIP events (bench.py roofline leg) ------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int id; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+bool sr3d_prof_active() { return g_prof_on; }
+
+void sr3d_prof_begin(int id, double flops, hipStream_t st, void** token) {
+  *token = nullptr;
+  if (!g_prof_on) return;
+  ProfRec* r = new ProfRec{nullptr, nullptr, flops, id};
+  if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
+  (void)hipEventRecord(r->a, st);
+  *token = r;
+}
+
+void sr3d_prof_end(void* token, hipStream_t st) {
+  if (!token) return;
+  ProfRec* r = (ProfRec*)token;
+  (void)hipEventRecord(r->b, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(*r);
+  delete r;
+}
+
 extern "C" {
+int sr3d_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return SR3D_OK;
+}
+
+int sr3d_profile_read(int kernel_id, double* ms, double* flops, long long* launches) {
+  SR3D_CHECK(ms && flops && launches, SR3D_E_ARG, "profile_read: null pointer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double t = 0, f = 0; long long n = 0;
+  for (auto& r : g_prof) {
+    if (r.id != kernel_id) continue;
+    SR3D_HIP(hipEventSynchronize(r.b));
+    float e = 0.f;
+    SR3D_HIP(hipEventElapsedTime(&e, r.a, r.b));
+    t += e; f += r.flops; n++;
+  }
+  *ms = t; *flops = f; *launches = n;
+  return SR3D_OK;
+}
+
 int sr3d_version(void) { return SR3D_VERSION; }
 const char* sr3d_last_error(void) { return g_err; }
 }

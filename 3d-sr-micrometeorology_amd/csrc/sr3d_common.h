@@ -42,6 +42,11 @@ void sr3d_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// per-kernel HIP-event timing (off unless sr3d_profile_enable(1)); ids are SR3D_PROF_*
+bool sr3d_prof_active();
+void sr3d_prof_begin(int id, double flops, hipStream_t st, void** token);
+void sr3d_prof_end(void* token, hipStream_t st);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channels, ChanCat* out, const char* what);

@@ -372,7 +372,16 @@ int launch(IgemmParams& p, int B, hipStream_t st) {
   }
   dim3 grid(p.ntz * p.nty * p.ntx, ceil_div(p.N, BN), B);
   SR3D_CHECK(grid.y <= 65535 && grid.z <= 65535, SR3D_E_ARG, "igemm: grid too large");
+  void* tok = nullptr;
+  if (sr3d_prof_active()) {
+    // algorithmic FLOPs of this launch: 2 * taps * K * (valid rows) * output voxels (no padding counted)
+    const double rows = p.epi == EPI_GATED ? 2.0 * p.Cg : (double)p.N;
+    const double flops = 2.0 * p.ntaps * p.K * rows * (double)p.OZ * p.OY * p.OX * B;
+    const int id = S_IN == 2 ? SR3D_PROF_IGEMM_S2 : (LO == 0 ? SR3D_PROF_IGEMM_BWD_S2 : SR3D_PROF_IGEMM_S1);
+    sr3d_prof_begin(id, flops, st, &tok);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

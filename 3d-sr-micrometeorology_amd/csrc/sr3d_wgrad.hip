@@ -302,6 +302,9 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   hipStream_t st = (hipStream_t)stream;
   constexpr int kLds1 = (int)WgradCfg<1, 2>::lds_bytes;
   constexpr int kLds2 = (int)WgradCfg<2, 1>::lds_bytes;
+  void* tok = nullptr;
+  if (sr3d_prof_active())
+    sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)OZ * OY * OX * d->B, st, &tok);
   if (d->stride == 1) {
     auto kern = wgrad_kernel<1, 2>;
     static thread_local bool cfg = false;
@@ -319,6 +322,7 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), kLds2, st, p);
   }
+  sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pl.cblk, n_total), dim3(256), 0, st, (const float*)workspace,
                      (float*)dw, pl.S, n_total, d->Cin, pl.Npad, pl.Cpad);

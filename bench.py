@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Training-step throughput of the voxel-SR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + loss + zero_grad + backward (+ gradient all-reduce for
+N > 1) + Adam of the reference's UNetSR (default.yml widths, 65.47 M parameters)
+on one synthetic batch, i.e. the body of reference
+pytorch/src/optim_helper.py:156-178.  Workload at every N = BASELINE.json
+configs[1]: LR (1,4,20,80,80) -> HR (1,4,80,320,320) per GPU, fp32, L1 loss
+(weak scaling: per-GPU batch fixed at 1).  ``--loss mixed`` switches to the
+physics-guided loss of configs[2]; ``--batch`` changes the per-GPU batch.
+
+Prints ONE JSON line (rank 0) with the metric, the roofline figure of the
+dominant kernel measured live with HIP events, and a CPU baseline (the oracle,
+timed on this host's cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per HR voxel per training step, default.yml widths
+FLOP_PER_VOXEL = 8_486_693
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+DEFAULT_CONFIG = {
+    "data": {"stds": [8.40, 14.40, 21.60, 7.00]},
+    "train": {"lr": 1.0e-4, "loss": {"name": "L1"}},
+    "model": {"model_name": "unet", "in_channels": 4, "out_channels": 4, "num_feat0": 64, "num_feat1": 128,
+              "num_feat2": 128, "num_feat3": 256, "num_feat4": 256, "num_x2upsample": 2, "num_latent_layers": 3,
+              "n_layers_in_block": 2, "bias_feat_extraction": False,
+              "conv_mode_feat_extraction": "g_conv_with_separated_bias",
+              "conv_mode_down_block": "g_conv_with_separated_bias", "conv_mode_up_block": None},
+}
+
+
+def make_config(loss: str) -> dict:
+    cfg = json.loads(json.dumps(DEFAULT_CONFIG))
+    if loss == "mixed":
+        cfg["train"]["loss"] = {"name": "MixedDivergenceGradientL2Loss", "weight_gradient_loss": 1.0,
+                                "weight_divergence_loss": 10.0}
+    return cfg
+
+
+def synthetic_batch(batch, hr, scale, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    Z, Y, X = hr
+    x = torch.rand(batch, 4, Z // scale, Y // scale, X // scale, generator=g)
+    y = torch.rand(batch, 4, Z, Y, X, generator=g)
+    b = (torch.rand(batch, 1, Z, Y, X, generator=g) > 0.2).float()
+    return x.to(device), b.to(device), y.to(device)
+
+
+def host_cores() -> int:
+    """cores this process may really use: the GPU box gives one GPU's share (16) of a 256-thread host"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """the CPU oracle (oracle/ref_cpu.py: stock ATen conv3d etc., pinned to the reference by
+    tests/golden) on the reference's own training crop size, timed on this host's cores"""
+    from oracle import ref_cpu as R
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    hr = (32, 64, 64)
+    sd = R.random_state_dict(cfg["model"], seed=42)
+    opt = R.AdamState(sd, lr=cfg["train"]["lr"])
+    x, b, y = synthetic_batch(1, hr, 4, 1234, "cpu")
+    R.train_step(sd, opt, cfg, x, b, y)  # warm-up (first call pays oneDNN primitive creation)
+    times = []
+    t_all = time.time()
+    while True:
+        t0 = time.time()
+        R.train_step(sd, opt, cfg, x, b, y)
+        times.append(time.time() - t0)
+        if len(times) >= 5 or time.time() - t_all + times[-1] > budget_s:
+            break
+    sec = sum(times) / len(times)
+    vox = hr[0] * hr[1] * hr[2]
+    return {"value": vox / sec, "unit": "HR voxels/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full training steps (fwd+loss+bwd+Adam, same model and loss) of the CPU oracle "
+                      f"on one HR {hr[0]}x{hr[1]}x{hr[2]} crop (LR 8x16x16), {sec:.2f} s/step; the 80x320x320 "
+                      f"volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="per-GPU batch")
+    ap.add_argument("--loss", choices=["l1", "mixed"], default="l1")
+    ap.add_argument("--lr-grid", type=int, nargs=3, default=[20, 80, 80], metavar=("Z", "Y", "X"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the sr3d engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import sr3d_amd
+    from sr3d_amd import _lib as L
+
+    cfg = make_config(args.loss)
+    scale = 2 ** cfg["model"]["num_x2upsample"]
+    hr = tuple(v * scale for v in args.lr_grid)
+    torch.manual_seed(42)
+    model = sr3d_amd.make_model(cfg).to(dev)
+    loss_fn = sr3d_amd.make_loss(cfg)
+    opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"])
+    reducer = None
+    if world > 1:
+        reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
+        reducer.broadcast_parameters(opt.flat_param)
+    x, b, y = synthetic_batch(args.batch, hr, scale, 1234 + rank, dev)
+
+    def step():
+        pred = model(x, b)
+        loss = loss_fn(pred, y, b)
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            opt.grad_scale = reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    L.lib.sr3d_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    last_loss = float(loss.detach())
+
+    # per-kernel HIP-event times collected during the timed steps
+    prof = {}
+    for name, kid in (("igemm_s1", 0), ("igemm_s2", 1), ("igemm_bwd_s2", 2), ("wgrad", 3)):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
+        L.check(L.lib.sr3d_profile_read(kid, C.byref(ms), C.byref(fl), C.byref(n)), "sr3d_profile_read")
+        prof[name] = {"ms": ms.value, "flops": fl.value, "launches": n.value}
+    L.lib.sr3d_profile_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        vox_per_step = world * args.batch * hr[0] * hr[1] * hr[2]
+        value = vox_per_step * args.steps / elapsed
+        dom = prof["igemm_s1"]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        per_kernel = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
+                      for k, v in prof.items()}
+        out = {
+            "metric": "training voxels/sec (fwd+bwd+loss) on 4x 3D SR",
+            "value": value,
+            "unit": "HR voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32",
+            "data": "synthetic",
+            "config": {"workload": f"LR {args.lr_grid[0]}x{args.lr_grid[1]}x{args.lr_grid[2]} -> 4x SR HR "
+                                   f"{hr[0]}x{hr[1]}x{hr[2]}, batch {args.batch}/GPU, fp32, UNetSR default.yml widths "
+                                   f"(65.47M params), {'L1' if args.loss == 'l1' else 'MixedDivergenceGradientL2'} "
+                                   f"loss, fwd+loss+bwd+Adam (BASELINE configs[{1 if args.loss == 'l1' else 2}])",
+                       "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "igemm_kernel<S_IN=1> (stride-1 conv forward + input gradient, fp32 MFMA 32x32x2)",
+                         "launches_per_step": dom["launches"] / args.steps,
+                         "kernel_ms_per_step": dom["ms"] / args.steps},
+            "step_tflops": FLOP_PER_VOXEL * value / 1e12,
+            "step_mfma_frac": FLOP_PER_VOXEL * value / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+            "kernels": per_kernel,
+            "loss": last_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,20 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
 int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* ---- measurement hook (bench.py's roofline leg; no reference counterpart) --------
+ * When enabled, every launch of the conv kernels is bracketed by two HIP events on the
+ * stream it is launched on.  sr3d_profile_read() returns, for one kernel family, the
+ * summed event time, the summed ALGORITHMIC FLOPs (2 * 27 * Cin * Cout * output voxels,
+ * padding not counted) and the number of launches since the last enable. */
+enum {
+  SR3D_PROF_IGEMM_S1 = 0,     /* stride-1 conv forward and stride-1 input gradient */
+  SR3D_PROF_IGEMM_S2 = 1,     /* stride-2 conv forward */
+  SR3D_PROF_IGEMM_BWD_S2 = 2, /* stride-2 input gradient (8 parity classes) */
+  SR3D_PROF_WGRAD = 3         /* weight gradient (main kernel, without the slab reduce) */
+};
+int sr3d_profile_enable(int on);
+int sr3d_profile_read(int kernel_id, double* ms, double* flops, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif
