@@ -44,6 +44,7 @@ struct IgemmParams {
   int s_out, pz, py, px;
   int unsh_C;          // unshuffle: channels of the result (= N / 8)
   int Cg;              // gated: width of one branch (channels of y / save_f / save_s)
+  int n_off;           // first GEMM row of this launch (a layer's rows may be covered by two launches)
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -52,26 +53,27 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
+// Workgroup = 4 waves that split the TZ*TY voxel rows of the tile; every wave holds RT row tiles
+// (32 output channels each) x CT voxel rows of 32 x.
+template <int S_IN, int LO, int HI, int TZ, int TY, int RT, int KC>
 struct IgemmCfg {
+  static constexpr int BN = 32 * RT;
   static constexpr int TX = 32;
   static constexpr int HZ = (TZ - 1) * S_IN + (HI - LO) + 1;
   static constexpr int HY = (TY - 1) * S_IN + (HI - LO) + 1;
   static constexpr int HX = (TX - 1) * S_IN + (HI - LO) + 1;
   static constexpr int HCH = HZ * HY * HX;
   static constexpr int HS = (KC * HCH + 3) & ~3;  // floats, keeps the weight image 16-B aligned
-  static constexpr int WM = 4 / WN;
-  static constexpr int RT = BN / WN / 32;
+  static constexpr int WM = 4;
   static constexpr int CT = TZ * TY / WM;
   static constexpr size_t lds_bytes(int ntaps) { return (size_t)(HS + ntaps * KC * BN) * 4; }
   static_assert(TZ * TY % WM == 0, "col tiles must split over waves");
-  static_assert(BN % (WN * 32) == 0, "row tiles must split over waves");
 };
 
-template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
+template <int S_IN, int LO, int HI, int TZ, int TY, int RT, int KC>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
-  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
-  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, RT = C::RT, CT = C::CT, WM = C::WM;
+  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, RT, KC>;
+  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, CT = C::CT, BN = C::BN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;
   float* Ws = lds + C::HS;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave / WM, wm = wave % WM;
+  const int wm = wave;
 
   int tile = blockIdx.x;
   const int tix = tile % p.ntx;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int a_lane = (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
+  const int a_lane = (lane >> 5) * BN + (lane & 31);
   const int b_lane = (lane >> 5) * HCH + (lane & 31) * S_IN;
   int b_ct[CT];
 #pragma unroll
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
   }
   const int wblock = p.ntaps * KC * BN;  // floats per (nblk, chunk)
-  const int ninstr = wblock / 256;       // 1 KiB LDS-DMA pieces
+  const int ninstr = (wblock + 255) / 256;  // 1 KiB LDS-DMA pieces (the last one may be partial: wblock % 128 == 0)
 
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     __syncthreads();  // everyone is done reading the previous chunk
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     {
       const float* gw = p.wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
       for (int i = wave; i < ninstr; i += 4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
+        if (i * 256 + lane * 4 < wblock)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(Ws + i * 256), 16, 0, 0);
     }
     // ---- input halo tile [KC][HZ][HY][HX], zero outside the grid / beyond K.
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
   // ------------------------------------------------------------------ epilogue
   const int ox = ox0 + (lane & 31);
-  const int nrow0 = nblk * BN + wn * (BN / WN) + 4 * (lane >> 5);
+  const int nrow0 = p.n_off + nblk * BN + 4 * (lane >> 5);
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
 
   if (p.epi == EPI_GATED) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
 #pragma unroll
         for (int i = 0; i < RT; i += 2) {
-          const int cbase = (nblk * BN + wn * (BN / WN) + i * 32) / 2 + 4 * (lane >> 5);
+          const int cbase = (p.n_off + nblk * BN + i * 32) / 2 + 4 * (lane >> 5);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int co = cbase + (r & 3) + 8 * (r >> 2);
@@ -262,16 +265,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 }
 
 // --------------------------------------------------------------------- packing
+// Packed image of one launch region: [nblk][chunk][tap][KC][BN] with BN = 32*RT.
+// A layer's rows are covered by (U / 4) blocks of 128 rows plus one block with the
+// remaining U % 4 row tiles, so no more than 31 padded rows are ever multiplied.
 struct PackParams {
   const float* w1;
   const float* w2;
   float* wp;
-  int Cout, Cin;  // of the physical (Cout, Cin, 27) tensors
+  int Cout, Cin;   // of the physical (Cout, Cin, 27) tensors
   int kind;
-  int K, N;       // logical GEMM dims
+  int K, N;        // logical GEMM dims (N counts compacted rows for the backward kinds)
   int nchunks, nblk, BN, KC;
+  int n_off;       // first logical row of this region
   int ntaps;
   int tap[SR3D_MAX_TAPS];  // original tap index (kz*3+ky)*3+kx of packed tap t
+  // backward kinds: logical row n -> input channel, rows of slices that need no gradient are skipped
+  int rbeg[SR3D_MAX_SRC + 1];  // first logical row of needed slice i
+  int cbeg[SR3D_MAX_SRC];      // its first input channel
 };
 
 __global__ void pack_kernel(const PackParams p) {
@@ -287,7 +297,7 @@ __global__ void pack_kernel(const PackParams p) {
     r /= p.ntaps;
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
-    const int n = nb * p.BN + nn, k = chunk * p.KC + kc;
+    const int n = p.n_off + nb * p.BN + nn, k = chunk * p.KC + kc;
     float v = 0.f;
     if (n < p.N && k < p.K) {
       const int tap = p.tap[t];
@@ -297,10 +307,11 @@ __global__ void pack_kernel(const PackParams p) {
         const int blk = n >> 5;
         const int co = (blk >> 1) * 32 + (n & 31);
         if (co < p.Cout) v = ((blk & 1) ? p.w2 : p.w1)[((long long)co * p.Cin + k) * 27 + tap];
-      } else if (p.kind == SR3D_PACK_BWD) {
-        v = p.w1[((long long)k * p.Cin + n) * 27 + tap];
       } else {
-        v = (k < p.Cout ? p.w1 + (long long)k * p.Cin * 27 : p.w2 + (long long)(k - p.Cout) * p.Cin * 27)[n * 27 + tap];
+        const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
+        const int ci = p.cbeg[si] + (n - p.rbeg[si]);
+        const float* w = k < p.Cout ? p.w1 + (long long)k * p.Cin * 27 : p.w2 + (long long)(k - p.Cout) * p.Cin * 27;
+        v = w[ci * 27 + tap];
       }
     }
     p.wp[e] = v;
@@ -308,25 +319,31 @@ __global__ void pack_kernel(const PackParams p) {
 }
 
 // ------------------------------------------------------------------ host side
-constexpr int kBN = 128, kKC = 4;
-
-struct Geometry {
-  int K, N, nblk, nchunks;
-};
+constexpr int kKC = 4;
 
 inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
 
-Geometry geometry(const sr3d_conv_desc_t* d, int kind) {
-  Geometry g;
-  switch (kind) {
-    case SR3D_PACK_FWD: g.K = d->Cin, g.N = d->Cout; break;
-    case SR3D_PACK_FWD_GATED: g.K = d->Cin, g.N = 2 * ((d->Cout + 31) / 32) * 32; break;
-    case SR3D_PACK_BWD: g.K = d->Cout, g.N = d->Cin; break;
-    default: g.K = 2 * d->Cout, g.N = d->Cin; break;
-  }
-  g.nblk = ceil_div(g.N, kBN);
-  g.nchunks = ceil_div(g.K, kKC);
-  return g;
+// how the N rows of a GEMM are cut into launches
+struct RowPlan {
+  int units;       // 32-row tiles
+  int nblk4;       // blocks of 4 tiles (RT = 4)
+  int rem;         // tiles in the last block (0..3)
+};
+
+RowPlan row_plan(int n_rows) {
+  RowPlan r;
+  r.units = ceil_div(n_rows, 32);
+  r.nblk4 = r.units / 4;
+  r.rem = r.units % 4;
+  return r;
+}
+
+inline size_t region_floats(int nblk, int nchunks, int ntaps, int rt) {
+  return (size_t)nblk * nchunks * ntaps * kKC * 32 * rt;
+}
+
+inline size_t image_floats(const RowPlan& r, int nchunks, int ntaps) {
+  return region_floats(r.nblk4, nchunks, ntaps, 4) + (r.rem ? region_floats(1, nchunks, ntaps, r.rem) : 0);
 }
 
 // stride-2 backward: taps of parity class (pz,py,px), in (kz,ky,kx) order
@@ -351,39 +368,67 @@ int class_taps(int cls, int* orig, int* dz, int* dy, int* dx) {
   return n;
 }
 
-size_t class_offset_floats(const Geometry& g, int cls) {
-  // packed images of the 8 parity classes are stored back to back
-  size_t off = 0;
-  int o[27], a[27], b[27], c[27];
-  for (int i = 0; i < cls; i++) off += (size_t)g.nblk * g.nchunks * class_taps(i, o, a, b, c) * kKC * kBN;
-  return off;
+int run_pack(PackParams p, const RowPlan& rp, float* image, hipStream_t st) {
+  // region A: nblk4 blocks of 128 rows; region B: one block of 32*rem rows
+  for (int region = 0; region < 2; region++) {
+    const int rt = region == 0 ? 4 : rp.rem;
+    const int nblk = region == 0 ? rp.nblk4 : (rp.rem ? 1 : 0);
+    if (nblk == 0) continue;
+    p.nblk = nblk, p.BN = 32 * rt, p.KC = kKC;
+    p.n_off = region == 0 ? 0 : rp.nblk4 * 128;
+    p.wp = image + (region == 0 ? 0 : region_floats(rp.nblk4, p.nchunks, p.ntaps, 4));
+    const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, p);
+    SR3D_HIP(hipGetLastError());
+  }
+  return SR3D_OK;
 }
 
-template <int S_IN, int LO, int HI, int TZ, int TY, int BN, int WN, int KC>
-int launch(IgemmParams& p, int B, hipStream_t st) {
-  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
+template <int S_IN, int LO, int HI, int TZ, int TY, int RT, int KC>
+int launch_one(IgemmParams& p, int B, int nblk, hipStream_t st) {
+  using C = IgemmCfg<S_IN, LO, HI, TZ, TY, RT, KC>;
   p.ntz = ceil_div(p.OZ, TZ), p.nty = ceil_div(p.OY, TY), p.ntx = ceil_div(p.OX, 32);
-  auto kern = igemm_kernel<S_IN, LO, HI, TZ, TY, BN, WN, KC>;
+  auto kern = igemm_kernel<S_IN, LO, HI, TZ, TY, RT, KC>;
   const size_t lds = C::lds_bytes(p.ntaps);
   static thread_local size_t configured = 0;
   if (lds > configured) {
     SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  dim3 grid(p.ntz * p.nty * p.ntx, ceil_div(p.N, BN), B);
+  dim3 grid(p.ntz * p.nty * p.ntx, nblk, B);
   SR3D_CHECK(grid.y <= 65535 && grid.z <= 65535, SR3D_E_ARG, "igemm: grid too large");
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+// all launches of one GEMM: region A with RT = 4, region B with RT = rem
+template <int S_IN, int LO, int HI, int TZ, int TY>
+int launch(IgemmParams p, int B, const RowPlan& rp, const float* image, hipStream_t st) {
   void* tok = nullptr;
   if (sr3d_prof_active()) {
-    // algorithmic FLOPs of this launch: 2 * taps * K * (valid rows) * output voxels (no padding counted)
+    // algorithmic FLOPs: 2 * taps * K * (valid rows) * output voxels (no padding counted)
     const double rows = p.epi == EPI_GATED ? 2.0 * p.Cg : (double)p.N;
     const double flops = 2.0 * p.ntaps * p.K * rows * (double)p.OZ * p.OY * p.OX * B;
     const int id = S_IN == 2 ? SR3D_PROF_IGEMM_S2 : (LO == 0 ? SR3D_PROF_IGEMM_BWD_S2 : SR3D_PROF_IGEMM_S1);
     sr3d_prof_begin(id, flops, st, &tok);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  int rc = SR3D_OK;
+  if (rp.nblk4 > 0) {
+    p.wp = image, p.n_off = 0;
+    rc = launch_one<S_IN, LO, HI, TZ, TY, 4, kKC>(p, B, rp.nblk4, st);
+  }
+  if (rc == SR3D_OK && rp.rem > 0) {
+    p.wp = image + region_floats(rp.nblk4, p.nchunks, p.ntaps, 4), p.n_off = rp.nblk4 * 128;
+    switch (rp.rem) {
+      case 1: rc = launch_one<S_IN, LO, HI, TZ, TY, 1, kKC>(p, B, 1, st); break;
+      case 2: rc = launch_one<S_IN, LO, HI, TZ, TY, 2, kKC>(p, B, 1, st); break;
+      default: rc = launch_one<S_IN, LO, HI, TZ, TY, 3, kKC>(p, B, 1, st); break;
+    }
+  }
   sr3d_prof_end(tok, st);
-  SR3D_HIP(hipGetLastError());
-  return SR3D_OK;
+  return rc;
 }
 
 void full_taps(IgemmParams& p, int HY, int HX, bool mirrored) {
@@ -407,8 +452,12 @@ int check_desc(const sr3d_conv_desc_t* d) {
   return SR3D_OK;
 }
 
+inline int fwd_rows(const sr3d_conv_desc_t* d, int kind) {
+  return kind == SR3D_PACK_FWD_GATED ? 2 * ((d->Cout + 31) / 32) * 32 : d->Cout;
+}
+
 int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, IgemmParams& p, int dst_scale,
-                   hipStream_t st) {
+                   const float* image, hipStream_t st) {
   const long long vox = (long long)d->Z * d->Y * d->X;
   if (int rc = sr3d_make_cat(x_srcs, n_src, vox, d->Cin, &p.in, "x_srcs")) return rc;
   for (int i = 0; i < p.in.n; i++) SR3D_CHECK(p.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
@@ -418,14 +467,15 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
   p.TZ_ = p.OZ * dst_scale, p.TY_ = p.OY * dst_scale, p.TX_ = p.OX * dst_scale;
   p.s_out = 1, p.pz = p.py = p.px = 0;
   p.nchunks = ceil_div(p.K, kKC);
+  const RowPlan rp = row_plan(p.N);
   if (d->stride == 1) {
-    using C = IgemmCfg<1, -1, 1, 2, 4, kBN, 2, kKC>;
+    using C = IgemmCfg<1, -1, 1, 2, 4, 4, kKC>;
     full_taps(p, C::HY, C::HX, false);
-    return launch<1, -1, 1, 2, 4, kBN, 2, kKC>(p, d->B, st);
+    return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
   }
-  using C = IgemmCfg<2, -1, 1, 1, 4, kBN, 2, kKC>;
+  using C = IgemmCfg<2, -1, 1, 1, 4, 4, kKC>;
   full_taps(p, C::HY, C::HX, false);
-  return launch<2, -1, 1, 1, 4, kBN, 2, kKC>(p, d->B, st);
+  return launch<2, -1, 1, 1, 4>(p, d->B, rp, image, st);
 }
 
 }  // namespace
@@ -433,42 +483,23 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
 extern "C" {
 
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
-  if (check_desc(d) != SR3D_OK || kind < 0 || kind > 3) return 0;
-  const Geometry g = geometry(d, kind);
-  if ((kind == SR3D_PACK_BWD || kind == SR3D_PACK_BWD_GATED) && d->stride == 2) return class_offset_floats(g, 8) * 4;
-  return (size_t)g.nblk * g.nchunks * 27 * kKC * kBN * 4;
+  if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
+  return image_floats(row_plan(fwd_rows(d, kind)), ceil_div(d->Cin, kKC), 27) * 4;
 }
 
 int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, const void* w_gate, void* w_packed,
                       void* stream) {
   if (int rc = check_desc(d)) return rc;
-  SR3D_CHECK(kind >= 0 && kind <= 3, SR3D_E_ARG, "pack: unknown kind %d", kind);
+  SR3D_CHECK(kind == SR3D_PACK_FWD || kind == SR3D_PACK_FWD_GATED, SR3D_E_ARG, "pack: unknown kind %d", kind);
   SR3D_CHECK(w_feat && w_packed, SR3D_E_ARG, "pack: null pointer");
-  const bool gated = kind == SR3D_PACK_FWD_GATED || kind == SR3D_PACK_BWD_GATED;
-  SR3D_CHECK(!gated || w_gate, SR3D_E_ARG, "pack: gated kind needs w_gate");
-  const Geometry g = geometry(d, kind);
+  SR3D_CHECK(kind != SR3D_PACK_FWD_GATED || w_gate, SR3D_E_ARG, "pack: gated kind needs w_gate");
   PackParams p{};
   p.w1 = (const float*)w_feat, p.w2 = (const float*)w_gate;
-  p.Cout = d->Cout, p.Cin = d->Cin, p.kind = kind, p.K = g.K, p.N = g.N;
-  p.nchunks = g.nchunks, p.nblk = g.nblk, p.BN = kBN, p.KC = kKC;
-  const bool bwd = kind == SR3D_PACK_BWD || kind == SR3D_PACK_BWD_GATED;
-  const int nimg = (bwd && d->stride == 2) ? 8 : 1;
-  for (int cls = 0; cls < nimg; cls++) {
-    int dz[27], dy[27], dx[27];
-    if (nimg == 8) {
-      p.ntaps = class_taps(cls, p.tap, dz, dy, dx);
-      p.wp = (float*)w_packed + class_offset_floats(g, cls);
-    } else {
-      p.ntaps = 27;
-      for (int t = 0; t < 27; t++) p.tap[t] = t;
-      p.wp = (float*)w_packed;
-    }
-    const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    SR3D_HIP(hipGetLastError());
-  }
-  return SR3D_OK;
+  p.Cout = d->Cout, p.Cin = d->Cin, p.kind = kind, p.K = d->Cin, p.N = fwd_rows(d, kind);
+  p.nchunks = ceil_div(p.K, kKC);
+  p.ntaps = 27;
+  for (int t = 0; t < 27; t++) p.tap[t] = t;
+  return run_pack(p, row_plan(p.N), (float*)w_packed, (hipStream_t)stream);
 }
 
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
@@ -477,7 +508,6 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "conv3d_fwd: null pointer");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "conv3d_fwd: unknown activation %d", act);
   IgemmParams p{};
-  p.wp = (const float*)w_packed;
   p.N = d->Cout;
   p.act = act;
   p.bias = (const float*)bias;
@@ -485,6 +515,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
   if (unshuffle) {
     SR3D_CHECK(d->Cout % 8 == 0, SR3D_E_ARG, "conv3d_fwd: unshuffle needs Cout %% 8 == 0 (got %d)", d->Cout);
     SR3D_CHECK(bias != nullptr, SR3D_E_ARG, "conv3d_fwd: unshuffle epilogue expects a bias");
+    SR3D_CHECK(d->stride == 1, SR3D_E_ARG, "conv3d_fwd: unshuffle epilogue is stride-1 only");
     p.epi = EPI_UNSHUFFLE;
     p.y = (float*)y;
     p.unsh_C = d->Cout / 8;
@@ -493,8 +524,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     sr3d_slice_t ys{y, d->Cout};
     if (int rc = sr3d_make_cat(&ys, 1, (long long)OZ * OY * OX, d->Cout, &p.out, "y")) return rc;
   }
-  if (unshuffle) SR3D_CHECK(d->stride == 1, SR3D_E_ARG, "conv3d_fwd: unshuffle epilogue is stride-1 only");
-  return forward_common(d, x_srcs, n_src, p, unshuffle ? 2 : 1, (hipStream_t)stream);
+  return forward_common(d, x_srcs, n_src, p, unshuffle ? 2 : 1, (const float*)w_packed, (hipStream_t)stream);
 }
 
 int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
@@ -505,52 +535,99 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
   SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_conv3d_fwd: unknown activation %d", act);
   IgemmParams p{};
-  p.wp = (const float*)w_packed;
   p.epi = EPI_GATED;
   p.act = act;
   p.bias = (const float*)bias_f, p.bias2 = (const float*)bias_g;
   p.y = (float*)y, p.save_f = (float*)save_f, p.save_s = (float*)save_s;
-  p.N = geometry(d, SR3D_PACK_FWD_GATED).N;  // GEMM rows: feature/gate interleaved in blocks of 32
+  p.N = fwd_rows(d, SR3D_PACK_FWD_GATED);  // GEMM rows: feature/gate interleaved in blocks of 32
   p.Cg = d->Cout;
-  return forward_common(d, x_srcs, n_src, p, 1, (hipStream_t)stream);
+  return forward_common(d, x_srcs, n_src, p, 1, (const float*)w_packed, (hipStream_t)stream);
 }
 
-int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_packed_bwd,
-                         const sr3d_slice_t* dx_dsts, int n_dst, void* stream) {
+// rows of the backward GEMM = input channels that need a gradient (slices with a null ptr are skipped)
+static int bwd_rows(const sr3d_slice_t* dx_dsts, int n_dst) {
+  int n = 0;
+  for (int i = 0; i < n_dst; i++)
+    if (dx_dsts[i].ptr) n += dx_dsts[i].channels;
+  return n;
+}
+
+size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy) {
+  if (check_desc(d) != SR3D_OK || (n_dy != 1 && n_dy != 2)) return 0;
+  // upper bound: every input channel needs a gradient; stride 2 stores the 8 parity-class images (27 taps in total)
+  return image_floats(row_plan(d->Cin), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
+}
+
+int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+                         const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   if (int rc = check_desc(d)) return rc;
-  SR3D_CHECK(w_packed_bwd, SR3D_E_ARG, "conv3d_bwd_data: null weight image");
-  SR3D_CHECK(n_dy == 1 || n_dy == 2, SR3D_E_ARG, "conv3d_bwd_data: n_dy must be 1 or 2");
+  SR3D_CHECK(w_feat && workspace && dx_dsts, SR3D_E_ARG, "conv3d_bwd_data: null pointer");
+  SR3D_CHECK(n_dy == 1 || (n_dy == 2 && w_gate), SR3D_E_ARG, "conv3d_bwd_data: n_dy must be 1, or 2 with w_gate");
+  SR3D_CHECK(n_dst >= 1 && n_dst <= SR3D_MAX_SRC, SR3D_E_ARG, "conv3d_bwd_data: need 1..4 destination slices");
+  SR3D_CHECK(workspace_bytes >= sr3d_conv3d_bwd_data_workspace_bytes(d, n_dy), SR3D_E_WORKSPACE,
+             "conv3d_bwd_data: workspace of %zu bytes is too small", workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
   const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
-  const int kind = n_dy == 2 ? SR3D_PACK_BWD_GATED : SR3D_PACK_BWD;
-  const Geometry g = geometry(d, kind);
+  const int K = n_dy * d->Cout;
+  // compacted destination list + row -> channel map
+  sr3d_slice_t need[SR3D_MAX_SRC];
+  PackParams pk{};
+  int nn = 0, ch = 0, rows = 0;
+  for (int i = 0; i <= SR3D_MAX_SRC; i++) pk.rbeg[i] = INT_MAX;
+  for (int i = 0; i < n_dst; i++) {
+    SR3D_CHECK(dx_dsts[i].channels > 0, SR3D_E_ARG, "dx_dsts[%d]: channels must be positive", i);
+    if (dx_dsts[i].ptr) {
+      need[nn] = dx_dsts[i];
+      pk.rbeg[nn] = rows, pk.cbeg[nn] = ch;
+      rows += dx_dsts[i].channels;
+      nn++;
+    }
+    ch += dx_dsts[i].channels;
+  }
+  SR3D_CHECK(ch == d->Cin, SR3D_E_ARG, "dx_dsts: slices hold %d channels, the layer has %d", ch, d->Cin);
+  if (rows == 0) return SR3D_OK;
+  SR3D_CHECK(rows == bwd_rows(dx_dsts, n_dst), SR3D_E_ARG, "internal: row count");
+
   IgemmParams p{};
-  if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)OZ * OY * OX, g.K, &p.in, "dy_srcs")) return rc;
+  if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)OZ * OY * OX, K, &p.in, "dy_srcs")) return rc;
   for (int i = 0; i < p.in.n; i++) SR3D_CHECK(p.in.ptr[i] != nullptr, SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
-  if (int rc = sr3d_make_cat(dx_dsts, n_dst, (long long)d->Z * d->Y * d->X, d->Cin, &p.out, "dx_dsts")) return rc;
-  p.K = g.K, p.N = g.N, p.nchunks = g.nchunks;
+  if (int rc = sr3d_make_cat(need, nn, (long long)d->Z * d->Y * d->X, rows, &p.out, "dx_dsts")) return rc;
+  p.K = K, p.N = rows, p.nchunks = ceil_div(K, kKC);
   p.IZ = OZ, p.IY = OY, p.IX = OX;
   p.TZ_ = d->Z, p.TY_ = d->Y, p.TX_ = d->X;
   p.epi = EPI_PLAIN, p.act = SR3D_ACT_NONE;
+  const RowPlan rp = row_plan(rows);
+
+  pk.w1 = (const float*)w_feat, pk.w2 = (const float*)w_gate;
+  pk.Cout = d->Cout, pk.Cin = d->Cin, pk.kind = n_dy == 2 ? SR3D_PACK_BWD_GATED : SR3D_PACK_BWD;
+  pk.K = K, pk.N = rows, pk.nchunks = p.nchunks;
+  float* image = (float*)workspace;
+
   if (d->stride == 1) {
-    p.wp = (const float*)w_packed_bwd;
+    pk.ntaps = 27;
+    for (int t = 0; t < 27; t++) pk.tap[t] = t;
+    if (int rc = run_pack(pk, rp, image, st)) return rc;
     p.OZ = d->Z, p.OY = d->Y, p.OX = d->X;
     p.s_out = 1;
-    using C = IgemmCfg<1, -1, 1, 2, 4, kBN, 2, kKC>;
+    using C = IgemmCfg<1, -1, 1, 2, 4, 4, kKC>;
     full_taps(p, C::HY, C::HX, true);
-    return launch<1, -1, 1, 2, 4, kBN, 2, kKC>(p, d->B, (hipStream_t)stream);
+    return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
   }
-  using C = IgemmCfg<1, 0, 1, 2, 4, kBN, 2, kKC>;
+  using C = IgemmCfg<1, 0, 1, 2, 4, 4, kKC>;
   for (int cls = 0; cls < 8; cls++) {
     IgemmParams q = p;
-    int orig[27], dz[27], dy[27], dx[27];
-    q.ntaps = class_taps(cls, orig, dz, dy, dx);
+    int dz[27], dy[27], dx[27];
+    pk.ntaps = q.ntaps = class_taps(cls, pk.tap, dz, dy, dx);
     for (int t = 0; t < q.ntaps; t++) q.tap_off[t] = (dz[t] * C::HY + dy[t]) * C::HX + dx[t];
-    q.wp = (const float*)w_packed_bwd + class_offset_floats(g, cls);
     q.pz = (cls >> 2) & 1, q.py = (cls >> 1) & 1, q.px = cls & 1;
     q.s_out = 2;
     q.OZ = (d->Z - q.pz + 1) / 2, q.OY = (d->Y - q.py + 1) / 2, q.OX = (d->X - q.px + 1) / 2;
-    if (q.OZ <= 0 || q.OY <= 0 || q.OX <= 0) continue;
-    if (int rc = launch<1, 0, 1, 2, 4, kBN, 2, kKC>(q, d->B, (hipStream_t)stream)) return rc;
+    if (q.OZ > 0 && q.OY > 0 && q.OX > 0) {
+      if (int rc = run_pack(pk, rp, image, st)) return rc;
+      if (int rc = launch<1, 0, 1, 2, 4>(q, d->B, rp, image, st)) return rc;
+    }
+    image += image_floats(rp, p.nchunks, q.ntaps);
   }
   return SR3D_OK;
 }

@@ -69,12 +69,13 @@ def _bwd_weight(desc: L.ConvDesc, srcs, dys) -> torch.Tensor:
 def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate) -> List[Optional[torch.Tensor]]:
     if not any(needs):
         return [None] * len(srcs)
-    kind = L.PACK_BWD_GATED if w_gate is not None else L.PACK_BWD
-    wp = pack_weights(desc, kind, w_feat, w_gate)
+    nbytes = L.lib.sr3d_conv3d_bwd_data_workspace_bytes(C.byref(desc), len(dys))
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dys[0].device)
     outs: List[Optional[torch.Tensor]] = [torch.empty_like(s) if n else None for s, n in zip(srcs, needs)]
     dsts = [o if o is not None else (int(s.shape[1]), None) for o, s in zip(outs, srcs)]
-    L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs"), len(dys), L.dev_ptr(wp),
-                                       L.slices(dsts, "dx_dsts"), len(dsts), L.stream_ptr()), "sr3d_conv3d_bwd_data")
+    L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs"), len(dys), L.dev_ptr(w_feat),
+                                       L.dev_ptr(w_gate), L.slices(dsts, "dx_dsts"), len(dsts), L.dev_ptr(ws), nbytes,
+                                       L.stream_ptr()), "sr3d_conv3d_bwd_data")
     return outs
 
 

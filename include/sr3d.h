@@ -57,12 +57,13 @@ typedef struct {
   int32_t stride; /* 1 or 2 */
 } sr3d_conv_desc_t;
 
-/* kinds of packed (MFMA-tile-ordered) weight images */
+/* kinds of packed (MFMA-tile-ordered) weight images; the two BWD kinds are built inside
+ * sr3d_conv3d_bwd_data (in its workspace) and are not accepted by sr3d_pack_weights */
 enum {
   SR3D_PACK_FWD = 0,        /* plain conv forward                              */
   SR3D_PACK_FWD_GATED = 1,  /* feature + gate branches interleaved by 32 rows  */
-  SR3D_PACK_BWD = 2,        /* transposed image for bwd_data                   */
-  SR3D_PACK_BWD_GATED = 3   /* K = [d_feat ; d_gate]                           */
+  SR3D_PACK_BWD = 2,        /* transposed image, rows = input channels that need a gradient */
+  SR3D_PACK_BWD_GATED = 3   /* same with K = [d_feat ; d_gate]                 */
 };
 
 int sr3d_version(void);
@@ -89,10 +90,15 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
                           void* stream);
 
 /* ---- backward (autograd of the above: optim_helper.py:165 loss.backward()) -- */
-/* dx_dsts[i] = slice i of d(cat(x))/ = conv_transpose(cat(dy_srcs); W)  (aten convolution_backward, input grad)
- * dy_srcs hold the gradient w.r.t. the PRE-activation conv outputs (1 slice, or 2 = [d_feat, d_gate]). */
-int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_packed_bwd,
-                         const sr3d_slice_t* dx_dsts, int n_dst, void* stream);
+/* dx_dsts[i] = slice i of d(cat(x)) = conv_transpose(cat(dy_srcs); W)  (aten convolution_backward, input grad)
+ * dy_srcs hold the gradient w.r.t. the PRE-activation conv outputs (1 slice, or 2 = [d_feat, d_gate]);
+ * w_feat / w_gate are the (Cout, Cin, 3,3,3) state_dict tensors (w_gate only when n_dy == 2).
+ * Destination slices with a NULL ptr (building mask, network input) are not computed at all: their rows
+ * are left out of the GEMM.  The workspace receives the transposed weight image. */
+size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy);
+int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+                         const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* dw[(n, c, kz,ky,kx)] over n in cat(dy_srcs) channels (so for gated layers dw = [dWf ; dWg]).
  * deterministic: fixed split of the voxel reduction + ordered second stage. */
