@@ -20,61 +20,103 @@ namespace {
 struct WgradParams {
   ChanCat x;
   ChanCat dy;
-  int Cin, N;
+  int Cin, N, J;       // J = Cin * 27 flattened (channel, tap) columns
   int IZ, IY, IX;
   int OZ, OY, OX;
   int nty, ntx;        // tiles per (y, x); z tiles = OZ
   long long ntiles;    // B * nty * ntx * OZ
   long long per_split; // tiles per workgroup
-  float* slab;
-  int Npad, Cpad;
+  float* slab;         // [S][Npad][Jpad]
+  int Npad, Jpad;
 };
 
-template <int S_IN, int TY>
+// WAVES_N waves split the rows (32 each), 4 / WAVES_N waves split the columns (7 tiles of 32 each)
+template <int S_IN, int TY, int WAVES_N>
 struct WgradCfg {
+  static constexpr int WAVES_C = 4 / WAVES_N;
+  static constexpr int CTW = 7;                         // column tiles per wave
+  static constexpr int COLS = WAVES_C * CTW * 32;       // columns per workgroup
+  static constexpr int ROWS = WAVES_N * 32;
+  static constexpr int NCH = (COLS + 26) / 27 + 1;      // channels a column block can touch
   static constexpr int HZ = 3;
   static constexpr int HY = (TY - 1) * S_IN + 3;
   static constexpr int HX = 31 * S_IN + 3;
   static constexpr int HCH = HZ * HY * HX;
-  static constexpr int PH = HCH | 1;      // odd pitch: 32 channels hit 32 banks
+  static constexpr int PH = HCH | 1;      // odd pitch
   static constexpr int VT = TY * 32;      // voxels per tile
   static constexpr int PV = VT + 1;
-  static constexpr int XS = 32 * PH;
-  static constexpr size_t lds_bytes = (size_t)(XS + 32 * PV) * 4;
+  static constexpr int XS = NCH * PH;
+  static constexpr int DS = ROWS * PV;
+  static constexpr int TBL = 2 * (NCH + ROWS);  // 64-bit entries: per-channel / per-row base offset and batch stride
+  static constexpr size_t lds_bytes = (size_t)(XS + DS) * 4 + (size_t)TBL * 8 + 16;
 };
 
-template <int S_IN, int TY>
+template <int S_IN, int TY, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
-  using C = WgradCfg<S_IN, TY>;
-  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, PH = C::PH, PV = C::PV, VT = C::VT;
+  using C = WgradCfg<S_IN, TY, WAVES_N>;
+  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, PH = C::PH, PV = C::PV, VT = C::VT, NCH = C::NCH;
+  constexpr int CTW = C::CTW, ROWS = C::ROWS, WAVES_C = C::WAVES_C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;
   float* Ds = lds + C::XS;
+  // tables of global pointers (sample 0) and per-sample strides, filled once
+  const float** xptr = reinterpret_cast<const float**>(lds + ((C::XS + C::DS + 3) & ~3));
+  long long* xbs = reinterpret_cast<long long*>(xptr + NCH);
+  const float** dptr = reinterpret_cast<const float**>(xbs + NCH);
+  long long* dbs = reinterpret_cast<long long*>(dptr + ROWS);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x, cb = blockIdx.y, nb = blockIdx.z;
+  const int wn = wave / WAVES_C, wc = wave % WAVES_C;
+  const int split = blockIdx.x, jb = blockIdx.y, nb = blockIdx.z;
   const long long IZYX = (long long)p.IZ * p.IY * p.IX;
   const long long OZYX = (long long)p.OZ * p.OY * p.OX;
+  const int j_begin = jb * C::COLS;
+  const int c_lo = j_begin / 27;
 
-  f32x16 acc[7];
+  if (tid < NCH) {
+    const int gc = c_lo + tid;
+    const float* ptr = nullptr;
+    long long bs = 0;
+    if (gc < p.Cin) {
+      const int si = cat_find(p.x, gc);
+      ptr = cat_ptr(p.x, si) + (long long)(gc - cat_cbeg(p.x, si)) * IZYX;
+      bs = cat_bstride(p.x, si);
+    }
+    xptr[tid] = ptr, xbs[tid] = bs;
+  } else if (tid >= 64 && tid < 64 + ROWS) {
+    const int r = tid - 64, gn = nb * ROWS + r;
+    const float* ptr = nullptr;
+    long long bs = 0;
+    if (gn < p.N) {
+      const int si = cat_find(p.dy, gn);
+      ptr = cat_ptr(p.dy, si) + (long long)(gn - cat_cbeg(p.dy, si)) * OZYX;
+      bs = cat_bstride(p.dy, si);
+    }
+    dptr[r] = ptr, dbs[r] = bs;
+  }
+
+  f32x16 acc[CTW];
 #pragma unroll
-  for (int t = 0; t < 7; t++)
+  for (int t = 0; t < CTW; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-  // LDS read bases: A = dY[n = lane&31][v + (lane>>5)], B = X[c = lane&31][pos + (lane>>5)*S + tap]
-  const int a_base = (lane & 31) * PV + (lane >> 5);
-  int b_base[7];
+  // LDS read bases: A = dY[n = lane&31][v + (lane>>5)], B = X[column = lane&31][pos + (lane>>5)*S]
+  // where a column is a (channel, tap) pair: its halo offset is fixed for the whole kernel
+  const int a_base = (wn * 32 + (lane & 31)) * PV + (lane >> 5);
+  int b_base[CTW];
 #pragma unroll
-  for (int t = 0; t < 7; t++) {
-    int tap = wave * 7 + t;
-    tap = tap > 26 ? 26 : tap;  // wave 3 has 6 real taps; the 7th is a dummy that is never stored
+  for (int t = 0; t < CTW; t++) {
+    int j = j_begin + (wc * CTW + t) * 32 + (lane & 31);
+    j = j < p.J ? j : p.J - 1;  // padded columns read something valid; they are never stored
+    const int c = j / 27, tap = j - c * 27;
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    b_base[t] = (lane & 31) * PH + (lane >> 5) * S_IN + (kz * HY + ky) * HX + kx;
+    b_base[t] = (c - c_lo) * PH + (lane >> 5) * S_IN + (kz * HY + ky) * HX + kx;
   }
 
   constexpr int NIX = (HCH + 255) / 256;
+  constexpr int PER = (ROWS * VT) / 256;  // dY elements per thread
 
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
@@ -91,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int oy0 = tiy * TY, ox0 = tix * 32;
     const int gz0 = oz * S_IN - 1, gy0 = oy0 * S_IN - 1, gx0 = ox0 * S_IN - 1;
 
-    __syncthreads();  // previous tile fully consumed
-    // ---- X halo [32 c][3][HY][HX]
+    __syncthreads();  // previous tile fully consumed (and, first time, the tables are written)
+    // ---- X halo [NCH][3][HY][HX]
     {
       int hoff[NIX];
 #pragma unroll
@@ -107,43 +149,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                         (unsigned)gx < (unsigned)p.IX;
         hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
       }
-      for (int c0 = 0; c0 < 32; c0 += 8) {
-        float v[8][NIX];
+      constexpr int CB = 6;  // channels in flight per batch
+      for (int c0 = 0; c0 < NCH; c0 += CB) {
+        float v[CB][NIX];
 #pragma unroll
-        for (int cc = 0; cc < 8; cc++) {
-          const int gc = cb * 32 + c0 + cc;
-          const float* base = nullptr;
-          if (gc < p.Cin) {
-            const int si = cat_find(p.x, gc);
-            base = p.x.ptr[si] + (long long)b * p.x.bstride[si] + (long long)(gc - p.x.cbeg[si]) * IZYX;
-          }
-#pragma unroll
-          for (int i = 0; i < NIX; i++) v[cc][i] = (base != nullptr && hoff[i] >= 0) ? base[hoff[i]] : 0.f;
-        }
-#pragma unroll
-        for (int cc = 0; cc < 8; cc++)
+        for (int cc = 0; cc < CB; cc++) {
+          const int cl = c0 + cc < NCH ? c0 + cc : NCH - 1;
+          const float* base = xptr[cl];
+          const long long bs = xbs[cl];
 #pragma unroll
           for (int i = 0; i < NIX; i++)
-            if (tid + i * 256 < HCH) Xs[(c0 + cc) * PH + tid + i * 256] = v[cc][i];
+            v[cc][i] = (base != nullptr && hoff[i] >= 0) ? base[(long long)b * bs + hoff[i]] : 0.f;
+        }
+#pragma unroll
+        for (int cc = 0; cc < CB; cc++)
+#pragma unroll
+          for (int i = 0; i < NIX; i++)
+            if (c0 + cc < NCH && tid + i * 256 < HCH) Xs[(c0 + cc) * PH + tid + i * 256] = v[cc][i];
       }
     }
-    // ---- dY tile [32 n][TY*32 voxels]
+    // ---- dY tile [ROWS n][TY*32 voxels]
     {
-      constexpr int PER = (32 * VT) / 256;  // elements per thread
       float v[PER];
 #pragma unroll
       for (int i = 0; i < PER; i++) {
         const int e = tid + i * 256;
         const int n = e / VT, vv = e % VT;
         const int oy = oy0 + vv / 32, ox = ox0 + (vv & 31);
-        const int gn = nb * 32 + n;
+        const float* base = dptr[n];
         float val = 0.f;
-        if (gn < p.N && oy < p.OY && ox < p.OX) {
-          const int si = cat_find(p.dy, gn);
-          const float* base = cat_ptr(p.dy, si) + (long long)b * cat_bstride(p.dy, si) +
-                              (long long)(gn - cat_cbeg(p.dy, si)) * OZYX;
-          val = base[((long long)oz * p.OY + oy) * p.OX + ox];
-        }
+        if (base != nullptr && oy < p.OY && ox < p.OX)
+          val = base[(long long)b * dbs[n] + ((long long)oz * p.OY + oy) * p.OX + ox];
         v[i] = val;
       }
 #pragma unroll
@@ -159,47 +195,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll 8
       for (int xx = 0; xx < 32; xx += 2) {
         const float a = Ds[a_base + row * 32 + xx];
-        float bv[7];
+        float bv[CTW];
 #pragma unroll
-        for (int t = 0; t < 7; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * HX + xx * S_IN];
+        for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * HX + xx * S_IN];
 #pragma unroll
-        for (int t = 0; t < 7; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
       }
     }
   }
 
-  // ---- partial block -> slab[split][tap][n][c]
-  const int c = cb * 32 + (lane & 31);
+  // ---- partial block -> slab[split][n][j]
 #pragma unroll
-  for (int t = 0; t < 7; t++) {
-    const int tap = wave * 7 + t;
-    if (tap > 26) continue;
-    float* dst = p.slab + (((long long)split * 27 + tap) * p.Npad + nb * 32) * p.Cpad + c;
+  for (int t = 0; t < CTW; t++) {
+    const int j = j_begin + (wc * CTW + t) * 32 + (lane & 31);
+    if (j >= p.Jpad) continue;
+    float* dst = p.slab + ((long long)split * p.Npad + nb * ROWS + wn * 32) * p.Jpad + j;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      dst[(long long)n * p.Cpad] = acc[t][r];
+      dst[(long long)n * p.Jpad] = acc[t][r];
     }
   }
 }
 
-// dW[n][c][t] = sum_s slab[s][t][n][c]; one workgroup per (n, 32 channels)
+// dW[n][j] = sum_s slab[s][n][j]  (fixed order: deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                          int S, int N, int Cin, int Npad, int Cpad) {
-  __shared__ float tile[32 * 27];
-  const int n = blockIdx.y, c0 = blockIdx.x * 32;
-  const long long plane = (long long)Npad * Cpad;
-  for (int e = threadIdx.x; e < 27 * 32; e += 256) {
-    const int t = e >> 5, cc = e & 31;
-    const float* src = slab + (long long)t * plane + (long long)n * Cpad + c0 + cc;
+                                                          int S, int N, int J, int Npad, int Jpad) {
+  const long long total = (long long)N * J;
+  const long long plane = (long long)Npad * Jpad;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / J), j = (int)(e - (long long)n * J);
+    const float* src = slab + (long long)n * Jpad + j;
     float s = 0.f;
-    for (int k = 0; k < S; k++) s += src[(long long)k * 27 * plane];
-    tile[cc * 27 + t] = s;
+    for (int k = 0; k < S; k++) s += src[(long long)k * plane];
+    dw[e] = s;
   }
-  __syncthreads();
-  const int nvalid = (Cin - c0 < 32 ? Cin - c0 : 32) * 27;
-  float* dst = dw + ((long long)n * Cin + c0) * 27;
-  for (int e = threadIdx.x; e < nvalid; e += 256) dst[e] = tile[e];
 }
 
 // db[c] = sum dy[b][c][:]  -- two deterministic stages
@@ -234,22 +265,30 @@ __global__ void bias_final_kernel(const float* __restrict__ part, float* __restr
 inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
 
 struct Plan {
-  int Npad, Cpad, nblk, cblk, ty, nty, ntx;
+  int waves_n;   // 1, 2 or 4
+  int Npad, Jpad, nblk, jblk, ty, nty, ntx;
   long long ntiles, per_split;
   int S;
 };
 
 Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   Plan pl;
-  pl.nblk = ceil_div(n_total, 32), pl.cblk = ceil_div(d->Cin, 32);
-  pl.Npad = pl.nblk * 32, pl.Cpad = pl.cblk * 32;
+  const int J = d->Cin * 27;
+  // few columns: let the waves split the rows instead (stride 2 always uses 2x2: its halo tile is large)
+  if (d->stride == 2)
+    pl.waves_n = 2;
+  else
+    pl.waves_n = J <= 224 ? 4 : (J <= 448 ? 2 : 1);
+  const int rows = 32 * pl.waves_n, cols = (4 / pl.waves_n) * 7 * 32;
+  pl.nblk = ceil_div(n_total, rows), pl.jblk = ceil_div(J, cols);
+  pl.Npad = pl.nblk * rows, pl.Jpad = ceil_div(J, 32) * 32;
   const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
   pl.ty = d->stride == 1 ? 2 : 1;
   pl.nty = ceil_div(OY, pl.ty), pl.ntx = ceil_div(OX, 32);
   pl.ntiles = (long long)d->B * pl.nty * pl.ntx * OZ;
   // enough workgroups to fill 256 CUs x 2 a few times over, but cap the slab at ~192 MiB
-  long long want = ceil_div(2048, pl.nblk * pl.cblk);
-  const long long slab_one = (long long)27 * pl.Npad * pl.Cpad * 4;
+  long long want = ceil_div(2048, pl.nblk * pl.jblk);
+  const long long slab_one = (long long)pl.Npad * pl.Jpad * 4;
   const long long cap = (192ll << 20) / slab_one;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -257,6 +296,20 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   pl.per_split = (pl.ntiles + want - 1) / want;
   pl.S = (int)((pl.ntiles + pl.per_split - 1) / pl.per_split);
   return pl;
+}
+
+template <int S_IN, int TY, int WAVES_N>
+int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t st) {
+  auto kern = wgrad_kernel<S_IN, TY, WAVES_N>;
+  constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N>::lds_bytes;
+  static thread_local bool cfg = false;
+  if (!cfg) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    cfg = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), kLds, st, p);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
 }
 
 int bias_splits(long long vox) {
@@ -271,7 +324,7 @@ extern "C" {
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total) {
   if (!d || d->Cin <= 0 || n_total <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
   const Plan pl = make_plan(d, n_total);
-  return (size_t)pl.S * 27 * pl.Npad * pl.Cpad * 4;
+  return (size_t)pl.S * pl.Npad * pl.Jpad * 4;
 }
 
 int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src,
@@ -284,7 +337,7 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   for (int i = 0; i < n_dy && i < SR3D_MAX_SRC; i++) n_total += dy_srcs[i].channels;
   SR3D_CHECK(n_total > 0, SR3D_E_ARG, "conv3d_bwd_weight: dy_srcs hold no channels");
   const Plan pl = make_plan(d, n_total);
-  SR3D_CHECK(workspace_bytes >= (size_t)pl.S * 27 * pl.Npad * pl.Cpad * 4, SR3D_E_WORKSPACE,
+  SR3D_CHECK(workspace_bytes >= (size_t)pl.S * pl.Npad * pl.Jpad * 4, SR3D_E_WORKSPACE,
              "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
   WgradParams p{};
   const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
@@ -292,40 +345,32 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)OZ * OY * OX, n_total, &p.dy, "dy_srcs")) return rc;
   for (int i = 0; i < p.x.n; i++) SR3D_CHECK(p.x.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
   for (int i = 0; i < p.dy.n; i++) SR3D_CHECK(p.dy.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
-  p.Cin = d->Cin, p.N = n_total;
+  p.Cin = d->Cin, p.N = n_total, p.J = d->Cin * 27;
   p.IZ = d->Z, p.IY = d->Y, p.IX = d->X;
   p.OZ = OZ, p.OY = OY, p.OX = OX;
   p.nty = pl.nty, p.ntx = pl.ntx, p.ntiles = pl.ntiles, p.per_split = pl.per_split;
-  p.slab = (float*)workspace, p.Npad = pl.Npad, p.Cpad = pl.Cpad;
-  dim3 grid(pl.S, pl.cblk, pl.nblk);
-  SR3D_CHECK(pl.cblk <= 65535 && pl.nblk <= 65535, SR3D_E_ARG, "conv3d_bwd_weight: too many channel blocks");
+  p.slab = (float*)workspace, p.Npad = pl.Npad, p.Jpad = pl.Jpad;
+  dim3 grid(pl.S, pl.jblk, pl.nblk);
+  SR3D_CHECK(pl.jblk <= 65535 && pl.nblk <= 65535, SR3D_E_ARG, "conv3d_bwd_weight: too many blocks");
   hipStream_t st = (hipStream_t)stream;
-  constexpr int kLds1 = (int)WgradCfg<1, 2>::lds_bytes;
-  constexpr int kLds2 = (int)WgradCfg<2, 1>::lds_bytes;
   void* tok = nullptr;
   if (sr3d_prof_active())
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)OZ * OY * OX * d->B, st, &tok);
-  if (d->stride == 1) {
-    auto kern = wgrad_kernel<1, 2>;
-    static thread_local bool cfg = false;
-    if (!cfg) {
-      SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1));
-      cfg = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), kLds1, st, p);
-  } else {
-    auto kern = wgrad_kernel<2, 1>;
-    static thread_local bool cfg = false;
-    if (!cfg) {
-      SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2));
-      cfg = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), kLds2, st, p);
-  }
+  int rc;
+  if (d->stride == 2)
+    rc = launch_wgrad<2, 1, 2>(p, grid, st);
+  else if (pl.waves_n == 4)
+    rc = launch_wgrad<1, 2, 4>(p, grid, st);
+  else if (pl.waves_n == 2)
+    rc = launch_wgrad<1, 2, 2>(p, grid, st);
+  else
+    rc = launch_wgrad<1, 2, 1>(p, grid, st);
   sr3d_prof_end(tok, st);
-  SR3D_HIP(hipGetLastError());
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pl.cblk, n_total), dim3(256), 0, st, (const float*)workspace,
-                     (float*)dw, pl.S, n_total, d->Cin, pl.Npad, pl.Cpad);
+  if (rc) return rc;
+  const long long total = (long long)n_total * p.J;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)dw, pl.S,
+                     n_total, p.J, pl.Npad, pl.Jpad);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
