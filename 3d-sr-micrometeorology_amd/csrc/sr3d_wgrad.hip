@@ -17,6 +17,8 @@
 
 namespace {
 
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+
 struct WgradParams {
   ChanCat x;
   ChanCat dy;
@@ -30,31 +32,39 @@ struct WgradParams {
   int Npad, Jpad;
 };
 
-// WAVES_N waves split the rows (32 each), 4 / WAVES_N waves split the columns (7 tiles of 32 each)
+// One 512-thread workgroup per CU: WAVES_N waves split the rows (32 each), 8 / WAVES_N waves split the
+// columns (7 tiles of 32 each); two waves per SIMD share one LDS image.
+// LDS image of the input: per channel 3 planes x HY rows, every row starts at the 16-byte aligned
+// voxel x0*S - 4 and is RW floats long, so it is filled with float4 loads / ds_write_b128.  Plane and
+// channel pitches are padded (multiples of 4 floats) so that 32 consecutive (channel, tap) columns hit
+// the banks at most 2-way.
 template <int S_IN, int TY, int WAVES_N>
 struct WgradCfg {
-  static constexpr int WAVES_C = 4 / WAVES_N;
+  static constexpr int WAVES_C = 8 / WAVES_N;
   static constexpr int CTW = 7;                         // column tiles per wave
   static constexpr int COLS = WAVES_C * CTW * 32;       // columns per workgroup
   static constexpr int ROWS = WAVES_N * 32;
   static constexpr int NCH = (COLS + 26) / 27 + 1;      // channels a column block can touch
-  static constexpr int HZ = 3;
   static constexpr int HY = (TY - 1) * S_IN + 3;
-  static constexpr int HX = 31 * S_IN + 3;
-  static constexpr int HCH = HZ * HY * HX;
-  static constexpr int PH = HCH | 1;      // odd pitch
-  static constexpr int VT = TY * 32;      // voxels per tile
+  static constexpr int RW = S_IN == 1 ? 40 : 68;        // floats per row: [x0*S - 4, x0*S - 4 + RW)
+  static constexpr int RQ = RW / 4;
+  static constexpr int PZ = S_IN == 1 ? (TY == 2 ? 164 : HY * RW + 4) : 204;
+  static constexpr int PH = S_IN == 1 ? (TY == 2 ? 500 : 3 * PZ + 8) : 612;
+  static constexpr int CHQ = 3 * HY * RQ;               // float4 pieces per channel
+  static constexpr int VT = TY * 32;                    // voxels per tile
   static constexpr int PV = VT + 1;
   static constexpr int XS = NCH * PH;
   static constexpr int DS = ROWS * PV;
-  static constexpr int TBL = 2 * (NCH + ROWS);  // 64-bit entries: per-channel / per-row base offset and batch stride
-  static constexpr size_t lds_bytes = (size_t)(XS + DS) * 4 + (size_t)TBL * 8 + 16;
+  static constexpr int TBL = 2 * (NCH + ROWS);  // 64-bit entries: per-channel / per-row base pointer and batch stride
+  static constexpr size_t lds_bytes = (size_t)((XS + DS + 3) & ~3) * 4 + (size_t)TBL * 8;
+  static_assert(HY * RW <= PZ && 3 * PZ <= PH, "pitches too small");
 };
 
-template <int S_IN, int TY, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+template <int S_IN, int TY, int WAVES_N, bool VEC>
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   using C = WgradCfg<S_IN, TY, WAVES_N>;
-  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, PH = C::PH, PV = C::PV, VT = C::VT, NCH = C::NCH;
+  constexpr int HY = C::HY, RW = C::RW, RQ = C::RQ, PZ = C::PZ, PH = C::PH, PV = C::PV, VT = C::VT, NCH = C::NCH;
+  constexpr int CHQ = C::CHQ;
   constexpr int CTW = C::CTW, ROWS = C::ROWS, WAVES_C = C::WAVES_C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;
@@ -112,17 +122,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     j = j < p.J ? j : p.J - 1;  // padded columns read something valid; they are never stored
     const int c = j / 27, tap = j - c * 27;
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    b_base[t] = (c - c_lo) * PH + (lane >> 5) * S_IN + (kz * HY + ky) * HX + kx;
+    b_base[t] = (c - c_lo) * PH + (lane >> 5) * S_IN + kz * PZ + ky * RW + kx + 3;
   }
 
-  constexpr int NIX = (HCH + 255) / 256;
-  constexpr int PER = (ROWS * VT) / 256;  // dY elements per thread
+  constexpr int NT = 512;
+  constexpr int NF = (NCH * CHQ + NT - 1) / NT;  // float4 pieces of the input image per thread
+  constexpr int PER = (ROWS * VT) / (4 * NT);    // float4 pieces of the dY tile per thread
+  static_assert((ROWS * VT) % (4 * NT) == 0, "dY tile must split into float4 per thread");
 
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
   if (t_end > p.ntiles) t_end = p.ntiles;
 
-  for (long long tile = t_begin; tile < t_end; tile++) {
+  // Software pipeline (issue early / write late): the global loads of tile i+1 are issued before the
+  // MFMA loop of tile i and only written to LDS after it, so their latency hides behind ~14k MFMA cycles.
+  f32x4 vx[NF];
+  f32x4 vd[PER];
+
+  auto load_tile = [&](long long tile) {
     long long r = tile;
     const int oz = (int)(r % p.OZ);
     r /= p.OZ;
@@ -131,75 +148,97 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int tiy = (int)(r % p.nty);
     const int b = (int)(r / p.nty);
     const int oy0 = tiy * TY, ox0 = tix * 32;
-    const int gz0 = oz * S_IN - 1, gy0 = oy0 * S_IN - 1, gx0 = ox0 * S_IN - 1;
-
-    __syncthreads();  // previous tile fully consumed (and, first time, the tables are written)
-    // ---- X halo [NCH][3][HY][HX]
-    {
-      int hoff[NIX];
+    const int gz0 = oz * S_IN - 1, gy0 = oy0 * S_IN - 1, xs0 = ox0 * S_IN - 4;
 #pragma unroll
-      for (int i = 0; i < NIX; i++) {
-        const int e = tid + i * 256;
-        const int hz = e / (HY * HX);
-        const int r2 = e - hz * (HY * HX);
-        const int hy = r2 / HX;
-        const int hx = r2 - hy * HX;
-        const int gz = gz0 + hz, gy = gy0 + hy, gx = gx0 + hx;
-        const bool ok = e < HCH && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY &&
-                        (unsigned)gx < (unsigned)p.IX;
-        hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
-      }
-      constexpr int CB = 6;  // channels in flight per batch
-      for (int c0 = 0; c0 < NCH; c0 += CB) {
-        float v[CB][NIX];
-#pragma unroll
-        for (int cc = 0; cc < CB; cc++) {
-          const int cl = c0 + cc < NCH ? c0 + cc : NCH - 1;
-          const float* base = xptr[cl];
-          const long long bs = xbs[cl];
-#pragma unroll
-          for (int i = 0; i < NIX; i++)
-            v[cc][i] = (base != nullptr && hoff[i] >= 0) ? base[(long long)b * bs + hoff[i]] : 0.f;
+    for (int i = 0; i < NF; i++) {
+      const int e = tid + i * NT;
+      const int c = e / CHQ, r1 = e - c * CHQ;
+      const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
+      const int hy = r2 / RQ, q = r2 - hy * RQ;
+      const int gz = gz0 + hz, gy = gy0 + hy, xs = xs0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < NCH * CHQ) {
+        // the table lives in LDS, so the compiler cannot tell these are global pointers: say so, or it
+        // emits flat loads, which also count on lgkmcnt and would be drained by the first LDS wait below
+        const gfloat_p base = (gfloat_p)xptr[c];
+        if (base != nullptr && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY) {
+          const gfloat_p row = base + (long long)b * xbs[c] + ((long long)gz * p.IY + gy) * p.IX;
+          if (VEC) {
+            if (xs >= 0 && xs + 3 < p.IX) v = *(const __attribute__((address_space(1))) f32x4*)(row + xs);
+          } else {
+            if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = row[xs + 0];
+            if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = row[xs + 1];
+            if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = row[xs + 2];
+            if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = row[xs + 3];
+          }
         }
-#pragma unroll
-        for (int cc = 0; cc < CB; cc++)
-#pragma unroll
-          for (int i = 0; i < NIX; i++)
-            if (c0 + cc < NCH && tid + i * 256 < HCH) Xs[(c0 + cc) * PH + tid + i * 256] = v[cc][i];
       }
+      vx[i] = v;
     }
-    // ---- dY tile [ROWS n][TY*32 voxels]
-    {
-      float v[PER];
 #pragma unroll
-      for (int i = 0; i < PER; i++) {
-        const int e = tid + i * 256;
-        const int n = e / VT, vv = e % VT;
-        const int oy = oy0 + vv / 32, ox = ox0 + (vv & 31);
-        const float* base = dptr[n];
-        float val = 0.f;
-        if (base != nullptr && oy < p.OY && ox < p.OX)
-          val = base[(long long)b * dbs[n] + ((long long)oz * p.OY + oy) * p.OX + ox];
-        v[i] = val;
+    for (int i = 0; i < PER; i++) {
+      const int e = (tid + i * NT) * 4;
+      const int n = e / VT, vv = e % VT;
+      const int oy = oy0 + vv / 32, ox = ox0 + (vv & 31);
+      const gfloat_p base = (gfloat_p)dptr[n];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (base != nullptr && oy < p.OY) {
+        const gfloat_p row = base + (long long)b * dbs[n] + ((long long)oz * p.OY + oy) * p.OX;
+        if (VEC) {
+          if (ox + 3 < p.OX) v = *(const __attribute__((address_space(1))) f32x4*)(row + ox);
+        } else {
+          if (ox + 0 < p.OX) v.x = row[ox + 0];
+          if (ox + 1 < p.OX) v.y = row[ox + 1];
+          if (ox + 2 < p.OX) v.z = row[ox + 2];
+          if (ox + 3 < p.OX) v.w = row[ox + 3];
+        }
       }
+      vd[i] = v;
+    }
+  };
+
+  __syncthreads();  // pointer tables are visible
+  if (t_begin < t_end) load_tile(t_begin);
+
+  for (long long tile = t_begin; tile < t_end; tile++) {
+    __syncthreads();  // previous tile fully consumed
 #pragma unroll
-      for (int i = 0; i < PER; i++) {
-        const int e = tid + i * 256;
-        Ds[(e / VT) * PV + (e % VT)] = v[i];
-      }
+    for (int i = 0; i < NF; i++) {
+      const int e = tid + i * NT;
+      const int c = e / CHQ, r1 = e - c * CHQ;
+      const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
+      const int hy = r2 / RQ, q = r2 - hy * RQ;
+      if (e < NCH * CHQ) *reinterpret_cast<f32x4*>(&Xs[c * PH + hz * PZ + hy * RW + 4 * q]) = vx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int e = (tid + i * NT) * 4;
+      float* d = &Ds[(e / VT) * PV + (e % VT)];  // PV is odd: scalar stores
+      d[0] = vd[i].x, d[1] = vd[i].y, d[2] = vd[i].z, d[3] = vd[i].w;
     }
     __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);  // in flight during the MFMA loop below
 
+    // MFMA loop, fragments double-buffered in registers: the LDS reads of k-step s+1 are issued before
+    // the 7 MFMAs of k-step s, so an in-order wave never waits on LDS latency
+    {
+      constexpr int KS = TY * 16;  // k-steps (2 voxels each) per tile
+      float a0, a1, b0[CTW], b1[CTW];
+      auto frag = [&](int s, float& a, float (&bv)[CTW]) {
+        const int row = s >> 4, xx = (s & 15) * 2;
+        a = Ds[a_base + row * 32 + xx];
 #pragma unroll
-    for (int row = 0; row < TY; row++) {
-#pragma unroll 8
-      for (int xx = 0; xx < 32; xx += 2) {
-        const float a = Ds[a_base + row * 32 + xx];
-        float bv[CTW];
+        for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * RW + xx * S_IN];
+      };
+      frag(0, a0, b0);
 #pragma unroll
-        for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * HX + xx * S_IN];
+      for (int s = 0; s < KS; s += 2) {
+        frag(s + 1, a1, b1);
 #pragma unroll
-        for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+        if (s + 2 < KS) frag(s + 2, a0, b0);
+#pragma unroll
+        for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
       }
     }
   }
@@ -265,7 +304,7 @@ __global__ void bias_final_kernel(const float* __restrict__ part, float* __restr
 inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
 
 struct Plan {
-  int waves_n;   // 1, 2 or 4
+  int waves_n;   // 2, 4 or 8
   int Npad, Jpad, nblk, jblk, ty, nty, ntx;
   long long ntiles, per_split;
   int S;
@@ -276,18 +315,18 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   const int J = d->Cin * 27;
   // few columns: let the waves split the rows instead (stride 2 always uses 2x2: its halo tile is large)
   if (d->stride == 2)
-    pl.waves_n = 2;
+    pl.waves_n = 4;
   else
-    pl.waves_n = J <= 224 ? 4 : (J <= 448 ? 2 : 1);
-  const int rows = 32 * pl.waves_n, cols = (4 / pl.waves_n) * 7 * 32;
+    pl.waves_n = J <= 224 ? 8 : (J <= 448 ? 4 : 2);
+  const int rows = 32 * pl.waves_n, cols = (8 / pl.waves_n) * 7 * 32;
   pl.nblk = ceil_div(n_total, rows), pl.jblk = ceil_div(J, cols);
   pl.Npad = pl.nblk * rows, pl.Jpad = ceil_div(J, 32) * 32;
   const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
   pl.ty = d->stride == 1 ? 2 : 1;
   pl.nty = ceil_div(OY, pl.ty), pl.ntx = ceil_div(OX, 32);
   pl.ntiles = (long long)d->B * pl.nty * pl.ntx * OZ;
-  // enough workgroups to fill 256 CUs x 2 a few times over, but cap the slab at ~192 MiB
-  long long want = ceil_div(2048, pl.nblk * pl.jblk);
+  // enough workgroups to fill the 256 CUs (one workgroup each) a few times over, slab capped at ~192 MiB
+  long long want = ceil_div(1280, pl.nblk * pl.jblk);
   const long long slab_one = (long long)pl.Npad * pl.Jpad * 4;
   const long long cap = (192ll << 20) / slab_one;
   if (want > cap) want = cap;
@@ -298,18 +337,34 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   return pl;
 }
 
-template <int S_IN, int TY, int WAVES_N>
-int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t st) {
-  auto kern = wgrad_kernel<S_IN, TY, WAVES_N>;
+template <int S_IN, int TY, int WAVES_N, bool VEC>
+int launch_wgrad_v(const WgradParams& p, dim3 grid, hipStream_t st) {
+  auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC>;
   constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N>::lds_bytes;
   static thread_local bool cfg = false;
   if (!cfg) {
     SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     cfg = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), kLds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
+}
+
+// 16-byte loads need rows that start and end on float4 boundaries and 16-byte aligned tensors
+bool vec_ok(const WgradParams& p) {
+  if (p.IX % 4 || p.OX % 4) return false;
+  for (int i = 0; i < p.x.n; i++)
+    if (reinterpret_cast<uintptr_t>(p.x.ptr[i]) & 15) return false;
+  for (int i = 0; i < p.dy.n; i++)
+    if (reinterpret_cast<uintptr_t>(p.dy.ptr[i]) & 15) return false;
+  return true;
+}
+
+template <int S_IN, int TY, int WAVES_N>
+int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t st) {
+  return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true>(p, grid, st)
+                   : launch_wgrad_v<S_IN, TY, WAVES_N, false>(p, grid, st);
 }
 
 int bias_splits(long long vox) {
@@ -358,13 +413,13 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)OZ * OY * OX * d->B, st, &tok);
   int rc;
   if (d->stride == 2)
-    rc = launch_wgrad<2, 1, 2>(p, grid, st);
+    rc = launch_wgrad<2, 1, 4>(p, grid, st);
+  else if (pl.waves_n == 8)
+    rc = launch_wgrad<1, 2, 8>(p, grid, st);
   else if (pl.waves_n == 4)
     rc = launch_wgrad<1, 2, 4>(p, grid, st);
-  else if (pl.waves_n == 2)
-    rc = launch_wgrad<1, 2, 2>(p, grid, st);
   else
-    rc = launch_wgrad<1, 2, 1>(p, grid, st);
+    rc = launch_wgrad<1, 2, 2>(p, grid, st);
   sr3d_prof_end(tok, st);
   if (rc) return rc;
   const long long total = (long long)n_total * p.J;
