@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--loss", choices=["l1", "mixed"], default="l1")
     ap.add_argument("--lr-grid", type=int, nargs=3, default=[20, 80, 80], metavar=("Z", "Y", "X"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and the bucketed all-reduce even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,9 +120,11 @@ def main():
         sys.exit("bench.py needs a GPU: the sr3d engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import sr3d_amd
     from sr3d_amd import _lib as L
@@ -133,7 +137,7 @@ def main():
     loss_fn = sr3d_amd.make_loss(cfg)
     opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"])
     reducer = None
-    if world > 1:
+    if use_dist:
         reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
         reducer.broadcast_parameters(opt.flat_param)
     x, b, y = synthetic_batch(args.batch, hr, scale, 1234 + rank, dev)
@@ -150,7 +154,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,7 +178,7 @@ def main():
     L.lib.sr3d_profile_enable(0)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -219,7 +223,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
