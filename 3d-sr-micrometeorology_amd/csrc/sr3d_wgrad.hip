@@ -15,6 +15,8 @@
 // [d_feat ; d_gate] of a gated layer yields dW = [dWf ; dWg] in one pass.
 #include "sr3d_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef const __attribute__((address_space(1))) float* gfloat_p;
@@ -30,6 +32,7 @@ struct WgradParams {
   long long per_split; // tiles per workgroup
   float* slab;         // [S][Npad][Jpad]
   int Npad, Jpad;
+  int dbg;             // timing experiments only (SR3D_WGRAD_DBG): 1 no global loads, 2 no LDS stores, 8 no MFMA
 };
 
 // One 512-thread workgroup per CU: WAVES_N waves split the rows (32 each), 8 / WAVES_N waves split the
@@ -126,64 +129,109 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   constexpr int NT = 512;
-  constexpr int NF = (NCH * CHQ + NT - 1) / NT;  // float4 pieces of the input image per thread
-  constexpr int PER = (ROWS * VT) / (4 * NT);    // float4 pieces of the dY tile per thread
+  // Input image staging: wave w owns channels w, w+8, ... of the block (channel = wave-uniform, so its
+  // global base pointer is scalar arithmetic); a channel's CHQ float4 pieces go to lanes (NJ per lane).
+  // Everything that depends only on the lane is computed here, once.
+  constexpr int CPW = (NCH + 7) / 8;        // channels per wave
+  constexpr int NJ = (CHQ + 63) / 64;       // float4 pieces per lane and channel
+  constexpr int PER = (ROWS * VT) / (4 * NT);  // float4 pieces of the dY tile per thread
   static_assert((ROWS * VT) % (4 * NT) == 0, "dY tile must split into float4 per thread");
+  int pz_[NJ], py_[NJ], pq_[NJ], rel_[NJ], ldso_[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int r1 = lane + 64 * j;
+    const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
+    const int hy = r2 / RQ, q = r2 - hy * RQ;
+    pz_[j] = r1 < CHQ ? hz : -100000;  // an out-of-range plane marks a lane without a piece
+    py_[j] = hy, pq_[j] = q;
+    rel_[j] = (hz * p.IY + hy) * p.IX + 4 * q;
+    ldso_[j] = hz * PZ + hy * RW + 4 * q;
+  }
+  f32x4 vx[CPW][NJ] = {};
+  f32x4 vd[PER] = {};
 
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
   if (t_end > p.ntiles) t_end = p.ntiles;
 
-  // Software pipeline (issue early / write late): the global loads of tile i+1 are issued before the
-  // MFMA loop of tile i and only written to LDS after it, so their latency hides behind ~14k MFMA cycles.
-  f32x4 vx[NF];
-  f32x4 vd[PER];
-
-  auto load_tile = [&](long long tile) {
-    long long r = tile;
-    const int oz = (int)(r % p.OZ);
+  // coordinates of the next tile to load: decomposed once (64-bit divisions are ~200 scalar
+  // instructions each), then advanced incrementally (z fastest, then x, y, sample)
+  int n_oz, n_tix, n_tiy, n_b;
+  {
+    long long r = t_begin;
+    n_oz = (int)(r % p.OZ);
     r /= p.OZ;
-    const int tix = (int)(r % p.ntx);
+    n_tix = (int)(r % p.ntx);
     r /= p.ntx;
-    const int tiy = (int)(r % p.nty);
-    const int b = (int)(r / p.nty);
-    const int oy0 = tiy * TY, ox0 = tix * 32;
-    const int gz0 = oz * S_IN - 1, gy0 = oy0 * S_IN - 1, xs0 = ox0 * S_IN - 4;
+    n_tiy = (int)(r % p.nty);
+    n_b = (int)(r / p.nty);
+  }
+
+  // ---- prefetch of the NEXT tile, cut into pieces that are issued between the MFMA groups of the current
+  // tile (a burst of 12 x 1 KiB loads per wave stalls the wave at the memory pipeline's issue queue for
+  // microseconds; two loads every other k-step pair are accepted at once).
+  int c_b, c_oz, c_oy0, c_ox0, c_off0;   // context of the tile being prefetched
+  bool c_ok[NJ];
+  int c_voff[NJ];
+
+  auto prep_next = [&]() {
+    c_oz = n_oz, c_b = n_b;
+    c_oy0 = n_tiy * TY, c_ox0 = n_tix * 32;
+    if (p.dbg & 4) c_oz = 1 + (blockIdx.x & 7), c_oy0 = 2 * TY, c_ox0 = 32, c_b = 0;  // timing experiment: always the same few tiles
+    if (++n_oz == p.OZ) {
+      n_oz = 0;
+      if (++n_tix == p.ntx) {
+        n_tix = 0;
+        if (++n_tiy == p.nty) n_tiy = 0, ++n_b;
+      }
+    }
+    const int gz0 = c_oz * S_IN - 1, gy0 = c_oy0 * S_IN - 1, xs0 = c_ox0 * S_IN - 4;
+    c_off0 = (gz0 * p.IY + gy0) * p.IX + xs0;
 #pragma unroll
-    for (int i = 0; i < NF; i++) {
-      const int e = tid + i * NT;
-      const int c = e / CHQ, r1 = e - c * CHQ;
-      const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
-      const int hy = r2 / RQ, q = r2 - hy * RQ;
-      const int gz = gz0 + hz, gy = gy0 + hy, xs = xs0 + 4 * q;
+    for (int j = 0; j < NJ; j++) {
+      const int xs = xs0 + 4 * pq_[j];
+      c_ok[j] = (unsigned)(gz0 + pz_[j]) < (unsigned)p.IZ && (unsigned)(gy0 + py_[j]) < (unsigned)p.IY;
+      if (VEC) c_ok[j] = c_ok[j] && xs >= 0 && xs + 3 < p.IX;
+      c_voff[j] = c_off0 + rel_[j];
+    }
+  };
+
+  auto load_x = [&](const int k) {   // piece k: channel wave + 8k of the block
+    const int cl = wave + 8 * k;     // wave-uniform
+    const int gc = c_lo + cl;
+    gfloat_p base = nullptr;
+    if (cl < NCH && gc < p.Cin && !(p.dbg & 1)) {
+      const int si = cat_find(p.x, gc);
+      base = (gfloat_p)cat_ptr(p.x, si) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < NCH * CHQ) {
-        // the table lives in LDS, so the compiler cannot tell these are global pointers: say so, or it
-        // emits flat loads, which also count on lgkmcnt and would be drained by the first LDS wait below
-        const gfloat_p base = (gfloat_p)xptr[c];
-        if (base != nullptr && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY) {
-          const gfloat_p row = base + (long long)b * xbs[c] + ((long long)gz * p.IY + gy) * p.IX;
-          if (VEC) {
-            if (xs >= 0 && xs + 3 < p.IX) v = *(const __attribute__((address_space(1))) f32x4*)(row + xs);
-          } else {
-            if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = row[xs + 0];
-            if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = row[xs + 1];
-            if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = row[xs + 2];
-            if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = row[xs + 3];
-          }
+      if (base != nullptr && c_ok[j]) {
+        if (VEC) {
+          v = *(const __attribute__((address_space(1))) f32x4*)(base + c_voff[j]);
+        } else {
+          const int xs = c_ox0 * S_IN - 4 + 4 * pq_[j];
+          if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = base[c_voff[j] + 0];
+          if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = base[c_voff[j] + 1];
+          if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = base[c_voff[j] + 2];
+          if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = base[c_voff[j] + 3];
         }
       }
-      vx[i] = v;
+      vx[k][j] = v;
     }
+  };
+
+  auto load_dy = [&]() {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const int e = (tid + i * NT) * 4;
       const int n = e / VT, vv = e % VT;
-      const int oy = oy0 + vv / 32, ox = ox0 + (vv & 31);
+      const int oy = c_oy0 + vv / 32, ox = c_ox0 + (vv & 31);
       const gfloat_p base = (gfloat_p)dptr[n];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (base != nullptr && oy < p.OY) {
-        const gfloat_p row = base + (long long)b * dbs[n] + ((long long)oz * p.OY + oy) * p.OX;
+      if (base != nullptr && oy < p.OY && !(p.dbg & 1)) {
+        const gfloat_p row = base + (long long)c_b * dbs[n] + ((long long)c_oz * p.OY + oy) * p.OX;
         if (VEC) {
           if (ox + 3 < p.OX) v = *(const __attribute__((address_space(1))) f32x4*)(row + ox);
         } else {
@@ -198,48 +246,77 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   };
 
   __syncthreads();  // pointer tables are visible
-  if (t_begin < t_end) load_tile(t_begin);
+  if (t_begin < t_end) {
+    prep_next();
+#pragma unroll
+    for (int k = 0; k < CPW; k++) load_x(k);
+    load_dy();
+  }
+
+  constexpr int KS = TY * 16;        // k-steps (2 voxels each) per tile
+  constexpr int NG = KS / 2;         // MFMA groups (2 k-steps each)
+  static_assert(NG >= CPW + 1, "not enough MFMA groups to spread the prefetch over");
+  constexpr int GSTEP = NG / (CPW + 1);  // a prefetch piece after every GSTEP-th group
 
   for (long long tile = t_begin; tile < t_end; tile++) {
     __syncthreads();  // previous tile fully consumed
+    if (!(p.dbg & 2) || tile == t_begin) {
 #pragma unroll
-    for (int i = 0; i < NF; i++) {
-      const int e = tid + i * NT;
-      const int c = e / CHQ, r1 = e - c * CHQ;
-      const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
-      const int hy = r2 / RQ, q = r2 - hy * RQ;
-      if (e < NCH * CHQ) *reinterpret_cast<f32x4*>(&Xs[c * PH + hz * PZ + hy * RW + 4 * q]) = vx[i];
-    }
+      for (int k = 0; k < CPW; k++) {
+        const int cl = wave + 8 * k;
+        if (cl < NCH) {
 #pragma unroll
-    for (int i = 0; i < PER; i++) {
-      const int e = (tid + i * NT) * 4;
-      float* d = &Ds[(e / VT) * PV + (e % VT)];  // PV is odd: scalar stores
-      d[0] = vd[i].x, d[1] = vd[i].y, d[2] = vd[i].z, d[3] = vd[i].w;
+          for (int j = 0; j < NJ; j++)
+            if (pz_[j] >= 0) *reinterpret_cast<f32x4*>(&Xs[cl * PH + ldso_[j]]) = vx[k][j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        const int e = (tid + i * NT) * 4;
+        float* d = &Ds[(e / VT) * PV + (e % VT)];  // PV is odd: scalar stores
+        d[0] = vd[i].x, d[1] = vd[i].y, d[2] = vd[i].z, d[3] = vd[i].w;
+      }
     }
     __syncthreads();
-    if (tile + 1 < t_end) load_tile(tile + 1);  // in flight during the MFMA loop below
+    const bool more = tile + 1 < t_end;
+    if (more) prep_next();
 
-    // MFMA loop, fragments double-buffered in registers: the LDS reads of k-step s+1 are issued before
-    // the 7 MFMAs of k-step s, so an in-order wave never waits on LDS latency
-    {
-      constexpr int KS = TY * 16;  // k-steps (2 voxels each) per tile
-      float a0, a1, b0[CTW], b1[CTW];
-      auto frag = [&](int s, float& a, float (&bv)[CTW]) {
-        const int row = s >> 4, xx = (s & 15) * 2;
-        a = Ds[a_base + row * 32 + xx];
+    // MFMA loop, fragments double-buffered in registers.  The sched_barriers keep the LDS reads of k-step
+    // s+1 ABOVE the MFMAs of k-step s (hipcc otherwise sinks them to just before their use).
+    auto frag = [&](int s, float& a, float (&bv)[CTW]) {
+      const int row = s >> 4, xx = (s & 15) * 2;
+      a = Ds[a_base + row * 32 + xx];
 #pragma unroll
-        for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * RW + xx * S_IN];
-      };
+      for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * RW + xx * S_IN];
+    };
+    if (!(p.dbg & 8)) {
+      float a0, a1, b0[CTW], b1[CTW];
       frag(0, a0, b0);
 #pragma unroll
-      for (int s = 0; s < KS; s += 2) {
+      for (int g = 0; g < NG; g++) {
+        const int s = 2 * g;
         frag(s + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < KS) frag(s + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && g % GSTEP == 0) {
+          const int piece = g / GSTEP;
+          if (piece < CPW)
+            load_x(piece);
+          else if (piece == CPW)
+            load_dy();
+        }
       }
+    } else if (more) {
+#pragma unroll
+      for (int k = 0; k < CPW; k++) load_x(k);
+      load_dy();
     }
   }
 
@@ -405,6 +482,10 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   p.OZ = OZ, p.OY = OY, p.OX = OX;
   p.nty = pl.nty, p.ntx = pl.ntx, p.ntiles = pl.ntiles, p.per_split = pl.per_split;
   p.slab = (float*)workspace, p.Npad = pl.Npad, p.Jpad = pl.Jpad;
+  {
+    static const int dbg = getenv("SR3D_WGRAD_DBG") ? atoi(getenv("SR3D_WGRAD_DBG")) : 0;
+    p.dbg = dbg;
+  }
   dim3 grid(pl.S, pl.jblk, pl.nblk);
   SR3D_CHECK(pl.jblk <= 65535 && pl.nblk <= 65535, SR3D_E_ARG, "conv3d_bwd_weight: too many blocks");
   hipStream_t st = (hipStream_t)stream;
