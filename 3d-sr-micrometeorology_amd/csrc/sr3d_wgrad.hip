@@ -41,10 +41,10 @@ struct WgradParams {
 // voxel x0*S - 4 and is RW floats long, so it is filled with float4 loads / ds_write_b128.  Plane and
 // channel pitches are padded (multiples of 4 floats) so that 32 consecutive (channel, tap) columns hit
 // the banks at most 2-way.
-template <int S_IN, int TY, int WAVES_N>
+template <int S_IN, int TY, int WAVES_N, int CTW_ = 7>
 struct WgradCfg {
   static constexpr int WAVES_C = 8 / WAVES_N;
-  static constexpr int CTW = 7;                         // column tiles per wave
+  static constexpr int CTW = CTW_;                      // column tiles per wave
   static constexpr int COLS = WAVES_C * CTW * 32;       // columns per workgroup
   static constexpr int ROWS = WAVES_N * 32;
   static constexpr int NCH = (COLS + 26) / 27 + 1;      // channels a column block can touch
@@ -63,9 +63,9 @@ struct WgradCfg {
   static_assert(HY * RW <= PZ && 3 * PZ <= PH, "pitches too small");
 };
 
-template <int S_IN, int TY, int WAVES_N, bool VEC>
+template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
-  using C = WgradCfg<S_IN, TY, WAVES_N>;
+  using C = WgradCfg<S_IN, TY, WAVES_N, CTW_>;
   constexpr int HY = C::HY, RW = C::RW, RQ = C::RQ, PZ = C::PZ, PH = C::PH, PV = C::PV, VT = C::VT, NCH = C::NCH;
   constexpr int CHQ = C::CHQ;
   constexpr int CTW = C::CTW, ROWS = C::ROWS, WAVES_C = C::WAVES_C;
@@ -334,6 +334,150 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient for layers with <= 4 output channels (the model's `last` conv, 69 -> 4): a 32-row MFMA
+// tile would be 7/8 padding, so this one runs on the VALU.  One workgroup owns ONE input channel and a
+// contiguous range of 4x8x32-voxel tiles; a thread owns one (y, x) column of 4 voxels and keeps all
+// 27 taps x 4 rows = 108 partial sums in registers (sliding 3-plane window through the LDS halo tile);
+// at the end the 256 threads are reduced (wave shuffles, then LDS) and written to slab[split][c][n][tap].
+struct SmallNParams {
+  ChanCat x;
+  const float* dy;     // (B, N, OZ, OY, OX), N <= 4
+  int Cin, N;
+  int Z, Y, X;         // stride 1: input grid = output grid
+  int ntz, nty, ntx;
+  long long ntiles, per_split;
+  float* slab;         // [S][Cin][4][27]
+};
+
+__global__ __launch_bounds__(256) void wgrad_smalln_kernel(const SmallNParams p) {
+  constexpr int TZ = 4, TY = 8, RW = 40, HY = TY + 2, HZ = TZ + 2;
+  constexpr int PZ = HY * RW;   // plane pitch (floats)
+  __shared__ __attribute__((aligned(16))) float Hs[HZ * PZ];
+  __shared__ float red[4 * 108];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;
+  const int split = blockIdx.x, c = blockIdx.y;
+  const long long ZYX = (long long)p.Z * p.Y * p.X;
+  const int si = cat_find(p.x, c);
+  const gfloat_p xbase0 = (gfloat_p)cat_ptr(p.x, si) + (long long)(c - cat_cbeg(p.x, si)) * ZYX;
+  const long long xbs = cat_bstride(p.x, si);
+  const bool vec = (p.X % 4 == 0) && ((reinterpret_cast<uintptr_t>(cat_ptr(p.x, si)) & 15) == 0);
+
+  float acc[4][27];
+#pragma unroll
+  for (int n = 0; n < 4; n++)
+#pragma unroll
+    for (int t = 0; t < 27; t++) acc[n][t] = 0.f;
+
+  const long long t_begin = (long long)split * p.per_split;
+  long long t_end = t_begin + p.per_split;
+  if (t_end > p.ntiles) t_end = p.ntiles;
+
+  for (long long tile = t_begin; tile < t_end; tile++) {
+    long long r = tile;
+    const int tiz = (int)(r % p.ntz);
+    r /= p.ntz;
+    const int tix = (int)(r % p.ntx);
+    r /= p.ntx;
+    const int tiy = (int)(r % p.nty);
+    const int b = (int)(r / p.nty);
+    const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * 32;
+    const gfloat_p xb = xbase0 + (long long)b * xbs;
+    __syncthreads();
+    // halo tile [6][10][40]: rows start at x0 - 4 (16-byte aligned)
+    for (int e = tid; e < HZ * HY * (RW / 4); e += 256) {
+      const int hz = e / (HY * (RW / 4)), r2 = e - hz * (HY * (RW / 4));
+      const int hy = r2 / (RW / 4), q = r2 - hy * (RW / 4);
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, xs = x0 - 4 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y) {
+        const gfloat_p row = xb + ((long long)gz * p.Y + gy) * p.X;
+        if (vec) {
+          if (xs >= 0 && xs + 3 < p.X) v = *(const __attribute__((address_space(1))) f32x4*)(row + xs);
+        } else {
+          if ((unsigned)(xs + 0) < (unsigned)p.X) v.x = row[xs + 0];
+          if ((unsigned)(xs + 1) < (unsigned)p.X) v.y = row[xs + 1];
+          if ((unsigned)(xs + 2) < (unsigned)p.X) v.z = row[xs + 2];
+          if ((unsigned)(xs + 3) < (unsigned)p.X) v.w = row[xs + 3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Hs[hz * PZ + hy * RW + 4 * q]) = v;
+    }
+    __syncthreads();
+    const int gy = y0 + ty, gx = x0 + tx;
+    const bool inb = gy < p.Y && gx < p.X;
+    const float* hp = &Hs[ty * RW + tx + 3];  // neighbour (kz,ky,kx) of voxel z: hp[(z+kz)*PZ + ky*RW + kx]
+#pragma unroll
+    for (int z = 0; z < TZ; z++) {
+      float d[4];
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        d[n] = 0.f;
+        if (inb && z0 + z < p.Z && n < p.N)
+          d[n] = p.dy[(((long long)b * p.N + n) * p.Z + z0 + z) * p.Y * p.X + (long long)gy * p.X + gx];
+      }
+#pragma unroll
+      for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const float xv = hp[(z + kz) * PZ + ky * RW + kx];
+#pragma unroll
+            for (int n = 0; n < 4; n++) acc[n][(kz * 3 + ky) * 3 + kx] += d[n] * xv;
+          }
+    }
+  }
+
+  // reduce the 256 threads: wave64 shuffles, then the 4 wave partials through LDS
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 4; n++)
+#pragma unroll
+    for (int t = 0; t < 27; t++) {
+      float v = acc[n][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[wave * 108 + n * 27 + t] = v;
+    }
+  __syncthreads();
+  if (tid < 108)
+    p.slab[((long long)split * p.Cin + c) * 108 + tid] = red[tid] + red[108 + tid] + red[216 + tid] + red[324 + tid];
+}
+
+// dW[n][c][t] = sum_s slab[s][c][n][t]
+__global__ void wgrad_smalln_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int N,
+                                           int Cin) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * Cin * 27) return;
+  const int n = e / (Cin * 27), r = e - n * Cin * 27, c = r / 27, t = r - c * 27;
+  float s = 0.f;
+  for (int k = 0; k < S; k++) s += slab[((long long)k * Cin + c) * 108 + n * 27 + t];
+  dw[e] = s;
+}
+
+struct SmallNPlan {
+  int ntz, nty, ntx, S;
+  long long ntiles, per_split;
+};
+
+SmallNPlan smalln_plan(const sr3d_conv_desc_t* d) {
+  SmallNPlan pl;
+  pl.ntz = ceil_div(d->Z, 4), pl.nty = ceil_div(d->Y, 8), pl.ntx = ceil_div(d->X, 32);
+  pl.ntiles = (long long)d->B * pl.ntz * pl.nty * pl.ntx;
+  long long want = ceil_div(6144, d->Cin);  // ~24 workgroups per CU in total
+  if (want > pl.ntiles) want = pl.ntiles;
+  if (want < 1) want = 1;
+  pl.per_split = (pl.ntiles + want - 1) / want;
+  pl.S = (int)((pl.ntiles + pl.per_split - 1) / pl.per_split);
+  return pl;
+}
+
+inline bool use_smalln(const sr3d_conv_desc_t* d, int n_total, int n_dy) {
+  return n_total <= 4 && n_dy == 1 && d->stride == 1 && d->Cin <= 65535;
+}
+
 // dW[n][j] = sum_s slab[s][n][j]  (fixed order: deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           int S, int N, int J, int Npad, int Jpad) {
@@ -382,6 +526,7 @@ inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
 
 struct Plan {
   int waves_n;   // 2, 4 or 8
+  int ctw;       // column tiles per wave: 7, or 3 for very few columns (conv0: 5 channels)
   int Npad, Jpad, nblk, jblk, ty, nty, ntx;
   long long ntiles, per_split;
   int S;
@@ -391,11 +536,14 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   Plan pl;
   const int J = d->Cin * 27;
   // few columns: let the waves split the rows instead (stride 2 always uses 2x2: its halo tile is large)
+  pl.ctw = 7;
   if (d->stride == 2)
     pl.waves_n = 4;
+  else if (J <= 192 && n_total > 64)
+    pl.waves_n = 4, pl.ctw = 3;   // 128 rows x 192 columns
   else
     pl.waves_n = J <= 224 ? 8 : (J <= 448 ? 4 : 2);
-  const int rows = 32 * pl.waves_n, cols = (8 / pl.waves_n) * 7 * 32;
+  const int rows = 32 * pl.waves_n, cols = (8 / pl.waves_n) * pl.ctw * 32;
   pl.nblk = ceil_div(n_total, rows), pl.jblk = ceil_div(J, cols);
   pl.Npad = pl.nblk * rows, pl.Jpad = ceil_div(J, 32) * 32;
   const int OZ = out_dim(d->Z, d->stride), OY = out_dim(d->Y, d->stride), OX = out_dim(d->X, d->stride);
@@ -414,10 +562,10 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   return pl;
 }
 
-template <int S_IN, int TY, int WAVES_N, bool VEC>
+template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_>
 int launch_wgrad_v(const WgradParams& p, dim3 grid, hipStream_t st) {
-  auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC>;
-  constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N>::lds_bytes;
+  auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC, CTW_>;
+  constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N, CTW_>::lds_bytes;
   static thread_local bool cfg = false;
   if (!cfg) {
     SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
@@ -438,10 +586,10 @@ bool vec_ok(const WgradParams& p) {
   return true;
 }
 
-template <int S_IN, int TY, int WAVES_N>
+template <int S_IN, int TY, int WAVES_N, int CTW_ = 7>
 int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t st) {
-  return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true>(p, grid, st)
-                   : launch_wgrad_v<S_IN, TY, WAVES_N, false>(p, grid, st);
+  return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true, CTW_>(p, grid, st)
+                   : launch_wgrad_v<S_IN, TY, WAVES_N, false, CTW_>(p, grid, st);
 }
 
 int bias_splits(long long vox) {
@@ -455,6 +603,7 @@ extern "C" {
 
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total) {
   if (!d || d->Cin <= 0 || n_total <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
+  if (use_smalln(d, n_total, 1)) return (size_t)smalln_plan(d).S * d->Cin * 108 * 4;
   const Plan pl = make_plan(d, n_total);
   return (size_t)pl.S * pl.Npad * pl.Jpad * 4;
 }
@@ -468,6 +617,32 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   int n_total = 0;
   for (int i = 0; i < n_dy && i < SR3D_MAX_SRC; i++) n_total += dy_srcs[i].channels;
   SR3D_CHECK(n_total > 0, SR3D_E_ARG, "conv3d_bwd_weight: dy_srcs hold no channels");
+  if (use_smalln(d, n_total, n_dy)) {
+    const SmallNPlan sp = smalln_plan(d);
+    SR3D_CHECK(workspace_bytes >= (size_t)sp.S * d->Cin * 108 * 4, SR3D_E_WORKSPACE,
+               "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+    SmallNParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.x, "x_srcs")) return rc;
+    for (int i = 0; i < q.x.n; i++) SR3D_CHECK(q.x.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    SR3D_CHECK(dy_srcs[0].ptr, SR3D_E_ARG, "dy_srcs[0].ptr is null");
+    q.dy = (const float*)dy_srcs[0].ptr, q.Cin = d->Cin, q.N = n_total;
+    q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.ntz = sp.ntz, q.nty = sp.nty, q.ntx = sp.ntx, q.ntiles = sp.ntiles, q.per_split = sp.per_split;
+    q.slab = (float*)workspace;
+    hipStream_t st2 = (hipStream_t)stream;
+    void* tok2 = nullptr;
+    if (sr3d_prof_active())
+      sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st2,
+                      &tok2);
+    hipLaunchKernelGGL(wgrad_smalln_kernel, dim3(sp.S, d->Cin), dim3(256), 0, st2, q);
+    sr3d_prof_end(tok2, st2);
+    SR3D_HIP(hipGetLastError());
+    const int total = n_total * d->Cin * 27;
+    hipLaunchKernelGGL(wgrad_smalln_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st2,
+                       (const float*)workspace, (float*)dw, sp.S, n_total, d->Cin);
+    SR3D_HIP(hipGetLastError());
+    return SR3D_OK;
+  }
   const Plan pl = make_plan(d, n_total);
   SR3D_CHECK(workspace_bytes >= (size_t)pl.S * pl.Npad * pl.Jpad * 4, SR3D_E_WORKSPACE,
              "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
@@ -495,6 +670,8 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   int rc;
   if (d->stride == 2)
     rc = launch_wgrad<2, 1, 4>(p, grid, st);
+  else if (pl.ctw == 3)
+    rc = launch_wgrad<1, 2, 4, 3>(p, grid, st);
   else if (pl.waves_n == 8)
     rc = launch_wgrad<1, 2, 8>(p, grid, st);
   else if (pl.waves_n == 4)
