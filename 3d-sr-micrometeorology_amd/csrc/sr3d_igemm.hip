@@ -264,6 +264,138 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------- small-N forward
+// Forward conv for layers with <= 4 output channels (the model's `last`, 69 -> 4): a 32-row MFMA tile
+// would be 7/8 padding, so this runs on the VALU.  Tile = 4x8x32 voxels, a thread owns 4 consecutive x
+// voxels x 4 output channels (16 accumulators); wave w stages input channel w of each 4-channel chunk
+// (float4 rows starting at x0-4); the weights [c][tap][4] are wave-uniform and come in by scalar loads.
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+
+struct SmallFwdParams {
+  ChanCat in;
+  int K, N;            // input channels, output channels (<= 4)
+  int Z, Y, X;
+  int ntz, nty, ntx;
+  const float* w;      // [K][27][4]
+  const float* bias;   // may be null
+  float* y;            // (B, N, Z, Y, X)
+  int act;
+};
+
+__global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p) {
+  constexpr int TZ = 4, TY = 8, RW = 40, RQ = RW / 4, HY = TY + 2, HZ = TZ + 2, KC = 4;
+  constexpr int PZ = HY * RW, PC = HZ * PZ;
+  __shared__ __attribute__((aligned(16))) float Hs[KC * PC];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xq = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
+  int tile = blockIdx.x;
+  const int tix = tile % p.ntx;
+  tile /= p.ntx;
+  const int tiy = tile % p.nty;
+  const int tiz = tile / p.nty;
+  const int b = blockIdx.y;
+  const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * 32;
+  const long long ZYX = (long long)p.Z * p.Y * p.X;
+  bool vec = p.X % 4 == 0;
+  for (int i = 0; i < p.in.n; i++) vec = vec && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 15) == 0;
+
+  float acc[4][4];  // [voxel i][channel n]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[i][n] = 0.f;
+
+  const int nchunks = (p.K + KC - 1) / KC;
+  for (int chunk = 0; chunk < nchunks; chunk++) {
+    __syncthreads();
+    {  // wave w stages channel chunk*4 + w
+      const int gc = chunk * KC + wave;
+      gfloat_p base = nullptr;
+      if (gc < p.K) {
+        const int si = cat_find(p.in, gc);
+        base = (gfloat_p)cat_ptr(p.in, si) + ((long long)(gc - cat_cbeg(p.in, si)) * ZYX + (long long)b * cat_bstride(p.in, si));
+      }
+      for (int e = lane; e < HZ * HY * RQ; e += 64) {
+        const int hz = e / (HY * RQ), r2 = e - hz * (HY * RQ);
+        const int hy = r2 / RQ, q = r2 - hy * RQ;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, xs = x0 - 4 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (base != nullptr && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y) {
+          const gfloat_p row = base + ((long long)gz * p.Y + gy) * p.X;
+          if (vec) {
+            if (xs >= 0 && xs + 3 < p.X) v = *(const __attribute__((address_space(1))) f32x4*)(row + xs);
+          } else {
+            if ((unsigned)(xs + 0) < (unsigned)p.X) v.x = row[xs + 0];
+            if ((unsigned)(xs + 1) < (unsigned)p.X) v.y = row[xs + 1];
+            if ((unsigned)(xs + 2) < (unsigned)p.X) v.z = row[xs + 2];
+            if ((unsigned)(xs + 3) < (unsigned)p.X) v.w = row[xs + 3];
+          }
+        }
+        *reinterpret_cast<f32x4*>(&Hs[wave * PC + hz * PZ + hy * RW + 4 * q]) = v;
+      }
+    }
+    __syncthreads();
+    const int cmax = p.K - chunk * KC < KC ? p.K - chunk * KC : KC;
+    for (int c = 0; c < cmax; c++) {
+      const float* wc = p.w + (long long)(chunk * KC + c) * 108;   // wave-uniform: scalar loads
+      const float* hc = &Hs[c * PC + tz * PZ + ty * RW + 4 * xq];
+#pragma unroll
+      for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          const float* hr = hc + kz * PZ + ky * RW;
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(hr);       // x0-4+4xq .. +3
+          const f32x4 h1 = *reinterpret_cast<const f32x4*>(hr + 4);   // .. +7
+          const float h8 = hr[8];
+          const float h[6] = {h0.w, h1.x, h1.y, h1.z, h1.w, h8};      // voxels x-1 .. x+4
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const float* wt = wc + ((kz * 3 + ky) * 3 + kx) * 4;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+              const float wv = wt[n];
+#pragma unroll
+              for (int i = 0; i < 4; i++) acc[i][n] += h[kx + i] * wv;
+            }
+          }
+        }
+    }
+  }
+
+  const int gz = z0 + tz, gy = y0 + ty, gx = x0 + 4 * xq;
+  if (gz < p.Z && gy < p.Y) {
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      if (n >= p.N) break;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      float* o = p.y + (((long long)b * p.N + n) * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
+      float r[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) r[i] = act_apply(acc[i][n] + bv, p.act);
+      if (vec && gx + 3 < p.X) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]};
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (gx + i < p.X) o[i] = r[i];
+      }
+    }
+  }
+}
+
+// w[(c*27 + t)*4 + n] = W[n][c][t]
+__global__ void pack_smalln_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * 108) return;
+  const int n = e & 3, r = e >> 2;  // r = c*27 + t
+  wp[e] = n < N ? w[(long long)n * K * 27 + r] : 0.f;
+}
+
+inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
+  return kind == SR3D_PACK_FWD && d->Cout <= 4 && d->stride == 1;
+}
+
 // --------------------------------------------------------------------- packing
 // Packed image of one launch region: [nblk][chunk][tap][KC][BN] with BN = 32*RT.
 // A layer's rows are covered by (U / 4) blocks of 128 rows plus one block with the
@@ -484,6 +616,7 @@ extern "C" {
 
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
+  if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
   return image_floats(row_plan(fwd_rows(d, kind)), ceil_div(d->Cin, kKC), 27) * 4;
 }
 
@@ -493,6 +626,12 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   SR3D_CHECK(kind == SR3D_PACK_FWD || kind == SR3D_PACK_FWD_GATED, SR3D_E_ARG, "pack: unknown kind %d", kind);
   SR3D_CHECK(w_feat && w_packed, SR3D_E_ARG, "pack: null pointer");
   SR3D_CHECK(kind != SR3D_PACK_FWD_GATED || w_gate, SR3D_E_ARG, "pack: gated kind needs w_gate");
+  if (use_smalln_fwd(d, kind)) {
+    hipLaunchKernelGGL(pack_smalln_kernel, dim3(ceil_div(d->Cin * 108, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)w_feat, (float*)w_packed, d->Cout, d->Cin);
+    SR3D_HIP(hipGetLastError());
+    return SR3D_OK;
+  }
   PackParams p{};
   p.w1 = (const float*)w_feat, p.w2 = (const float*)w_gate;
   p.Cout = d->Cout, p.Cin = d->Cin, p.kind = kind, p.K = d->Cin, p.N = fwd_rows(d, kind);
@@ -507,6 +646,18 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "conv3d_fwd: null pointer");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "conv3d_fwd: unknown activation %d", act);
+  if (use_smalln_fwd(d, SR3D_PACK_FWD) && !unshuffle) {
+    SmallFwdParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
+    for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    q.K = d->Cin, q.N = d->Cout, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.ntz = ceil_div(d->Z, 4), q.nty = ceil_div(d->Y, 8), q.ntx = ceil_div(d->X, 32);
+    q.w = (const float*)w_packed, q.bias = (const float*)bias, q.y = (float*)y, q.act = act;
+    SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_fwd: batch too large");
+    hipLaunchKernelGGL(smalln_fwd_kernel, dim3(q.ntz * q.nty * q.ntx, d->B), dim3(256), 0, (hipStream_t)stream, q);
+    SR3D_HIP(hipGetLastError());
+    return SR3D_OK;
+  }
   IgemmParams p{};
   p.N = d->Cout;
   p.act = act;

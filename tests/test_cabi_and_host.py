@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_not_crashes(eng):
     assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 0
     rc = lib.sr3d_pack_weights(C.byref(d), L.PACK_FWD, None, None, None, None)
     assert rc == -1 and b"stride" in lib.sr3d_last_error()
-    d = L.conv_desc(1, 4, 4, 8, 8, 8, 1)
+    d = L.conv_desc(1, 4, 8, 8, 8, 8, 1)
     rc = lib.sr3d_conv3d_fwd(C.byref(d), None, 0, None, None, None, 0, 0, None)
     assert rc == -1 and lib.sr3d_last_error() != b""
     rc = lib.sr3d_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
@@ -49,7 +49,9 @@ def test_argument_errors_are_reported_not_crashes(eng):
     with pytest.raises(RuntimeError, match="failed"):
         L.check(rc, "sr3d_adam_step")
     # workspace queries are pure host arithmetic
-    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 1 * 27 * 4 * 32 * 4
+    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 1 * 27 * 4 * 32 * 4   # one 32-row tile
+    d4 = L.conv_desc(1, 69, 4, 8, 8, 8, 1)   # <= 4 output channels: the VALU path's [Cin][27][4] image
+    assert lib.sr3d_packed_weight_bytes(C.byref(d4), L.PACK_FWD) == 69 * 27 * 4 * 4
     assert lib.sr3d_conv3d_bwd_weight_workspace_bytes(C.byref(d), 4) > 0
     assert lib.sr3d_loss_workspace_bytes(1, 8, 8, 8) >= 2 * 512 * 4
 
