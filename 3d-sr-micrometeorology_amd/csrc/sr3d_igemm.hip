@@ -455,18 +455,23 @@ constexpr int kKC = 4;
 
 inline int out_dim(int z, int s) { return (z - 1) / s + 1; }
 
-// how the N rows of a GEMM are cut into launches
+// How the N rows of a GEMM are cut into launches: `nblk` blocks of `rt` row tiles (32 rows each) plus one
+// block with the remaining `rem` tiles.  rt = 4 gives the most operand reuse; when the spatial grid is so
+// small that 4-tile blocks would leave CUs idle (levels 2-4 of the U-Net at batch 1), finer blocks are used.
 struct RowPlan {
   int units;       // 32-row tiles
-  int nblk4;       // blocks of 4 tiles (RT = 4)
-  int rem;         // tiles in the last block (0..3)
+  int rt;          // tiles per main block: 4, 2 or 1
+  int nblk;        // main blocks
+  int rem;         // tiles in the last block (0 .. rt-1)
 };
 
-RowPlan row_plan(int n_rows) {
+RowPlan row_plan(int n_rows, long long ntiles, bool pairs, int rt_max = 4) {
   RowPlan r;
   r.units = ceil_div(n_rows, 32);
-  r.nblk4 = r.units / 4;
-  r.rem = r.units % 4;
+  r.rt = rt_max;
+  while (r.rt > (pairs ? 2 : 1) && ntiles * ceil_div(r.units, r.rt) < 1024) r.rt /= 2;
+  r.nblk = r.units / r.rt;
+  r.rem = r.units % r.rt;
   return r;
 }
 
@@ -474,8 +479,10 @@ inline size_t region_floats(int nblk, int nchunks, int ntaps, int rt) {
   return (size_t)nblk * nchunks * ntaps * kKC * 32 * rt;
 }
 
-inline size_t image_floats(const RowPlan& r, int nchunks, int ntaps) {
-  return region_floats(r.nblk4, nchunks, ntaps, 4) + (r.rem ? region_floats(1, nchunks, ntaps, r.rem) : 0);
+inline size_t image_floats(int units, int nchunks, int ntaps) { return region_floats(units, nchunks, ntaps, 1); }
+
+inline long long tiles_of(int B, int oz, int oy, int ox, int tz, int ty) {
+  return (long long)B * ceil_div(oz, tz) * ceil_div(oy, ty) * ceil_div(ox, 32);
 }
 
 // stride-2 backward: taps of parity class (pz,py,px), in (kz,ky,kx) order
@@ -501,14 +508,14 @@ int class_taps(int cls, int* orig, int* dz, int* dy, int* dx) {
 }
 
 int run_pack(PackParams p, const RowPlan& rp, float* image, hipStream_t st) {
-  // region A: nblk4 blocks of 128 rows; region B: one block of 32*rem rows
+  // region A: nblk blocks of 32*rt rows; region B: one block of 32*rem rows
   for (int region = 0; region < 2; region++) {
-    const int rt = region == 0 ? 4 : rp.rem;
-    const int nblk = region == 0 ? rp.nblk4 : (rp.rem ? 1 : 0);
+    const int rt = region == 0 ? rp.rt : rp.rem;
+    const int nblk = region == 0 ? rp.nblk : (rp.rem ? 1 : 0);
     if (nblk == 0) continue;
     p.nblk = nblk, p.BN = 32 * rt, p.KC = kKC;
-    p.n_off = region == 0 ? 0 : rp.nblk4 * 128;
-    p.wp = image + (region == 0 ? 0 : region_floats(rp.nblk4, p.nchunks, p.ntaps, 4));
+    p.n_off = region == 0 ? 0 : rp.nblk * rp.rt * 32;
+    p.wp = image + (region == 0 ? 0 : region_floats(rp.nblk, p.nchunks, p.ntaps, rp.rt));
     const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -547,12 +554,16 @@ int launch(IgemmParams p, int B, const RowPlan& rp, const float* image, hipStrea
     sr3d_prof_begin(id, flops, st, &tok);
   }
   int rc = SR3D_OK;
-  if (rp.nblk4 > 0) {
+  if (rp.nblk > 0) {
     p.wp = image, p.n_off = 0;
-    rc = launch_one<S_IN, LO, HI, TZ, TY, 4, kKC>(p, B, rp.nblk4, st);
+    switch (rp.rt) {
+      case 4: rc = launch_one<S_IN, LO, HI, TZ, TY, 4, kKC>(p, B, rp.nblk, st); break;
+      case 2: rc = launch_one<S_IN, LO, HI, TZ, TY, 2, kKC>(p, B, rp.nblk, st); break;
+      default: rc = launch_one<S_IN, LO, HI, TZ, TY, 1, kKC>(p, B, rp.nblk, st); break;
+    }
   }
   if (rc == SR3D_OK && rp.rem > 0) {
-    p.wp = image + region_floats(rp.nblk4, p.nchunks, p.ntaps, 4), p.n_off = rp.nblk4 * 128;
+    p.wp = image + region_floats(rp.nblk, p.nchunks, p.ntaps, rp.rt), p.n_off = rp.nblk * rp.rt * 32;
     switch (rp.rem) {
       case 1: rc = launch_one<S_IN, LO, HI, TZ, TY, 1, kKC>(p, B, 1, st); break;
       case 2: rc = launch_one<S_IN, LO, HI, TZ, TY, 2, kKC>(p, B, 1, st); break;
@@ -588,6 +599,13 @@ inline int fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 2 * ((d->Cout + 31) / 32) * 32 : d->Cout;
 }
 
+// the forward launch plan depends only on the descriptor, so sr3d_pack_weights and sr3d_*_fwd agree on it
+RowPlan fwd_plan(const sr3d_conv_desc_t* d, int rows, bool gated) {
+  const int oz = out_dim(d->Z, d->stride), oy = out_dim(d->Y, d->stride), ox = out_dim(d->X, d->stride);
+  // stride 2: the halo tile is 2x larger per voxel; 64-row blocks keep two workgroups resident per CU
+  return row_plan(rows, tiles_of(d->B, oz, oy, ox, d->stride == 1 ? 2 : 1, 4), gated, d->stride == 1 ? 4 : 2);
+}
+
 int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, IgemmParams& p, int dst_scale,
                    const float* image, hipStream_t st) {
   const long long vox = (long long)d->Z * d->Y * d->X;
@@ -599,7 +617,7 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
   p.TZ_ = p.OZ * dst_scale, p.TY_ = p.OY * dst_scale, p.TX_ = p.OX * dst_scale;
   p.s_out = 1, p.pz = p.py = p.px = 0;
   p.nchunks = ceil_div(p.K, kKC);
-  const RowPlan rp = row_plan(p.N);
+  const RowPlan rp = fwd_plan(d, p.N, p.epi == EPI_GATED);
   if (d->stride == 1) {
     using C = IgemmCfg<1, -1, 1, 2, 4, 4, kKC>;
     full_taps(p, C::HY, C::HX, false);
@@ -617,7 +635,7 @@ extern "C" {
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
-  return image_floats(row_plan(fwd_rows(d, kind)), ceil_div(d->Cin, kKC), 27) * 4;
+  return image_floats(ceil_div(fwd_rows(d, kind), 32), ceil_div(d->Cin, kKC), 27) * 4;
 }
 
 int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, const void* w_gate, void* w_packed,
@@ -638,7 +656,7 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   p.nchunks = ceil_div(p.K, kKC);
   p.ntaps = 27;
   for (int t = 0; t < 27; t++) p.tap[t] = t;
-  return run_pack(p, row_plan(p.N), (float*)w_packed, (hipStream_t)stream);
+  return run_pack(p, fwd_plan(d, p.N, kind == SR3D_PACK_FWD_GATED), (float*)w_packed, (hipStream_t)stream);
 }
 
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
@@ -706,7 +724,7 @@ static int bwd_rows(const sr3d_slice_t* dx_dsts, int n_dst) {
 size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy) {
   if (check_desc(d) != SR3D_OK || (n_dy != 1 && n_dy != 2)) return 0;
   // upper bound: every input channel needs a gradient; stride 2 stores the 8 parity-class images (27 taps in total)
-  return image_floats(row_plan(d->Cin), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
+  return image_floats(ceil_div(d->Cin, 32), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
 }
 
 int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
@@ -748,7 +766,9 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   p.IZ = OZ, p.IY = OY, p.IX = OX;
   p.TZ_ = d->Z, p.TY_ = d->Y, p.TX_ = d->X;
   p.epi = EPI_PLAIN, p.act = SR3D_ACT_NONE;
-  const RowPlan rp = row_plan(rows);
+  const RowPlan rp = row_plan(rows, d->stride == 1 ? tiles_of(d->B, d->Z, d->Y, d->X, 2, 4)
+                                                   : tiles_of(d->B, (d->Z + 1) / 2, (d->Y + 1) / 2, (d->X + 1) / 2, 2, 4),
+                              false);
 
   pk.w1 = (const float*)w_feat, pk.w2 = (const float*)w_gate;
   pk.Cout = d->Cout, pk.Cin = d->Cin, pk.kind = n_dy == 2 ? SR3D_PACK_BWD_GATED : SR3D_PACK_BWD;
@@ -778,7 +798,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
       if (int rc = run_pack(pk, rp, image, st)) return rc;
       if (int rc = launch<1, 0, 1, 2, 4>(q, d->B, rp, image, st)) return rc;
     }
-    image += image_floats(rp, p.nchunks, q.ntaps);
+    image += image_floats(rp.units, p.nchunks, q.ntaps);
   }
   return SR3D_OK;
 }
