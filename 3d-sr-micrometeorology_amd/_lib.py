@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
 
 
 # every symbol include/sr3d.h declares: name -> (restype, argtypes)
-_P, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_P, _I, _LL, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_size_t
 _DESC, _SL = C.POINTER(ConvDesc), C.POINTER(Slice)
 SYMBOLS = {
     "sr3d_version": (_I, []),
@@ -53,7 +53,7 @@ SYMBOLS = {
     "sr3d_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
-    "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _I, _F, _P]),
+    "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),
     "sr3d_profile_enable": (_I, [_I]),
     "sr3d_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

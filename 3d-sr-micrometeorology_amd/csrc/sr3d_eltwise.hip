@@ -179,12 +179,11 @@ __global__ __launch_bounds__(kThreads) void near_wall_kernel(const float* __rest
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
 __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
-                                                        float step_size, float inv_bc2_sqrt, float b1, float b2,
-                                                        float eps, float gscale) {
+                                                        float step_size, float inv_bc2_sqrt, float w1, float b2,
+                                                        float w2, float eps, float gscale) {
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const float w1 = 1.f - b1, w2 = 1.f - b2;
   for (long long i = i0; i < n4; i += stride) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -293,19 +292,19 @@ int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* 
   return SR3D_OK;
 }
 
-int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
-                   float beta2, float eps, int step, float grad_scale, void* stream) {
+int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, double lr, double beta1,
+                   double beta2, double eps, int step, double grad_scale, void* stream) {
   SR3D_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, SR3D_E_ARG, "adam_step: bad argument");
   SR3D_ALIGN_CHECK(param, "adam_step");
   SR3D_ALIGN_CHECK(grad, "adam_step");
   SR3D_ALIGN_CHECK(exp_avg, "adam_step");
   SR3D_ALIGN_CHECK(exp_avg_sq, "adam_step");
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
-                     (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt, beta1, beta2,
-                     eps, grad_scale);
+                     (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

@@ -142,9 +142,10 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
                                    void* terms_out, void* dLdp, void* workspace, void* stream);
 
 /* ---- optimizer -------------------------------------------------------------- */
-/* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based. */
-int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, float lr,
-                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based.  The
+ * hyper-parameters are doubles, as in torch (1 - beta2 must be formed in double to match it). */
+int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, double lr,
+                   double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
 
 /* ---- measurement hook (bench.py's roofline leg; no reference counterpart) --------
  * When enabled, every launch of the conv kernels is bracketed by two HIP events on the

@@ -1,0 +1,166 @@
+"""Parity at BASELINE.json's full grid (HR 80x320x320) through size-independent
+properties: locality (a crop of the full-size result equals the oracle run on
+the cropped input), linearity / support of the gradients, determinism.  The CPU
+oracle only ever sees small crops, so this stays within seconds."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import relerr
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FULL = (80, 320, 320)
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available()
+    import sr3d_amd
+    return sr3d_amd
+
+
+def _crop(t, lo, hi):
+    return t[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+
+
+@pytest.mark.parametrize("stride,gated", [(1, True), (2, True), (1, False)])
+def test_forward_locality_at_full_size(eng, stride, gated):
+    """conv at 80x320x320 vs oracle on crops that touch a corner, an edge and the interior"""
+    g = torch.Generator().manual_seed(11 + stride)
+    cin_a, cout = 12, 40
+    xa = torch.rand(1, cin_a, *FULL, generator=g) - 0.5
+    xb = (torch.rand(1, 1, *FULL, generator=g) > 0.2).float()          # mask slice of the virtual concat
+    wf = torch.randn(cout, cin_a + 1, 3, 3, 3, generator=g) * 0.1
+    wg = torch.randn(cout, cin_a + 1, 3, 3, 3, generator=g) * 0.1
+    bg = torch.randn(cout, generator=g) * 0.1
+    if gated:
+        y = eng.ops.gated_conv3d_act([xa.to(DEV), xb.to(DEV)], wf.to(DEV), wg.to(DEV), None, bg.to(DEV), act="relu",
+                                     stride=stride).cpu()
+    else:
+        y = eng.ops.conv3d_act([xa.to(DEV), xb.to(DEV)], wf.to(DEV), bg.to(DEV), act="lrelu", stride=stride).cpu()
+    x = torch.cat([xa, xb], 1)
+    # output windows [lo, hi) on the OUTPUT grid
+    for lo, hi in [((0, 0, 0), (6, 10, 40)), ((70 // stride, 300 // stride, 280 // stride), tuple(f // stride for f in FULL)),
+                   ((31 // stride, 157 // stride, 95 // stride), (31 // stride + 5, 157 // stride + 7, 95 // stride + 33))]:
+        ilo = [max(0, l * stride - 1) for l in lo]
+        ihi = [min(f, (h - 1) * stride + 2) for h, f in zip(hi, FULL)]
+        xc = _crop(x, ilo, ihi)
+        # pad so that the crop's own zero padding coincides with the true border only where it is a true border
+        pad = []
+        for d in (2, 1, 0):
+            pad += [1 if lo[d] * stride - 1 < 0 else 0, 1 if (hi[d] - 1) * stride + 2 > FULL[d] else 0]
+        xc = F.pad(xc, pad)
+        if gated:
+            ref = torch.sigmoid(F.conv3d(xc, wg, bg, stride=stride)) * F.relu(F.conv3d(xc, wf, None, stride=stride))
+        else:
+            ref = F.leaky_relu(F.conv3d(xc, wf, bg, stride=stride), 0.01)
+        got = _crop(y, lo, hi)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert relerr(got, ref) < TOL
+
+
+def test_backward_support_and_values_at_full_size(eng):
+    """dy is non-zero only in a window: dx must vanish outside its 1-voxel dilation and, like dW, equal the
+    oracle evaluated on the cropped problem (both gradients are linear in dy)"""
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 20, 33
+    x = (torch.rand(1, cin, *FULL, generator=g) - 0.5)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1)
+    lo, hi = (40, 100, 200), (46, 109, 233)
+    dy = torch.zeros(1, cout, *FULL)
+    dy[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = torch.rand(1, cout, 6, 9, 33, generator=g) - 0.5
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y = eng.ops.conv3d_act([xd], wd, None, act=None)
+    y.backward(dy.to(DEV))
+    dx, dw = xd.grad.cpu(), wd.grad.cpu()
+    ilo, ihi = [l - 1 for l in lo], [h + 1 for h in hi]
+    outside = dx.clone()
+    outside[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1], ilo[2]:ihi[2]] = 0
+    assert float(outside.abs().max()) == 0.0
+    # oracle on the crop (window + halo), no padding needed: the window is interior
+    xc = _crop(x, ilo, ihi).clone().requires_grad_(True)
+    wc = w.clone().requires_grad_(True)
+    F.conv3d(xc, wc, None).backward(_crop(dy, lo, hi))
+    assert relerr(_crop(dx, ilo, ihi), xc.grad) < TOL
+    assert relerr(dw, wc.grad) < TOL
+
+
+def test_unshuffle_conv_full_level1(eng):
+    """UpBlock.up at level 1 (40x160x160 -> 80x320x320): crop of the scattered output vs oracle"""
+    g = torch.Generator().manual_seed(9)
+    cin = 9
+    x = torch.rand(1, cin, 40, 160, 160, generator=g) - 0.5
+    w = torch.randn(8 * cin, cin, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(8 * cin, generator=g) * 0.1
+    y = eng.ops.conv3d_act([x.to(DEV)], w.to(DEV), b.to(DEV), act="lrelu", unshuffle=True).cpu()
+    assert tuple(y.shape) == (1, cin, 80, 320, 320)
+    lo, hi = (17, 60, 96), (23, 66, 130)     # coarse window, interior
+    xc = _crop(x, [l - 1 for l in lo], [h + 1 for h in hi])
+    ref = R.unshuffle_voxels(F.leaky_relu(F.conv3d(xc, w, b), 0.01), 2)
+    got = _crop(y, [2 * l for l in lo], [2 * h for h in hi])
+    assert relerr(got, ref) < TOL
+
+
+def test_losses_at_full_size(eng):
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(1, 4, *FULL, generator=g)
+    t = torch.rand(1, 4, *FULL, generator=g)
+    b = (torch.rand(1, 1, *FULL, generator=g) > 0.2).float()
+    scales = [14.4, 21.6, 7.0]
+    pd = p.to(DEV).requires_grad_(True)
+    terms = eng.ops.MixedLossFn.apply(pd, t.to(DEV), b.to(DEV), scales, 5.0, 1.0, 10.0)
+    terms[3].backward()
+    pr = p.clone().requires_grad_(True)
+    ref_terms = R.mixed_div_grad_terms(pr, t, b, 1.0, 10.0, scales)
+    ref_total = ref_terms[0] + 1.0 * ref_terms[1] + 10.0 * ref_terms[2]
+    ref_total.backward()
+    for a, r in zip(terms[:3].tolist(), ref_terms):
+        assert abs(a - float(r)) < TOL * abs(float(r))
+    assert abs(float(terms[3]) - float(ref_total)) < TOL * float(ref_total)
+    assert relerr(pd.grad, pr.grad) < TOL
+    pd2 = p.to(DEV).requires_grad_(True)
+    l1 = eng.ops.L1LossFn.apply(pd2, t.to(DEV))
+    l1.backward()
+    assert abs(float(l1) - float((p - t).abs().mean())) < TOL * float(l1)
+    assert relerr(pd2.grad, torch.sign(p - t) / p.numel()) < 1e-6
+
+
+def test_fused_adam_65m_parameters(eng):
+    n = 65_472_736
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(n, generator=g) * 0.05
+    grads = [torch.randn(n, generator=g) * 1e-3 for _ in range(2)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-4)
+    pd = p0.to(DEV)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step, gr in enumerate(grads, 1):
+        ref_p.grad = gr.clone()
+        opt.step()
+        eng.ops.adam_step_(pd, gr.to(DEV), m, v, 1e-4, 0.9, 0.999, 1e-8, step)
+    assert relerr(pd.cpu() - p0, ref_p.detach() - p0) < 1e-5    # the UPDATE, not just the weights
+    assert relerr(m.cpu(), opt.state[ref_p]["exp_avg"]) < 1e-6
+    assert relerr(v.cpu(), opt.state[ref_p]["exp_avg_sq"]) < 1e-6
+
+
+def test_training_step_is_bit_reproducible(eng):
+    """two identical steps from the same state give identical gradients (deterministic wgrad / reductions);
+    default.yml widths on a reduced grid to keep the test short"""
+    import bench
+    cfg = bench.make_config("mixed")
+    torch.manual_seed(0)
+    model = eng.make_model(cfg).to(DEV)
+    loss_fn = eng.make_loss(cfg)
+    x, b, y = bench.synthetic_batch(1, (16, 64, 64), 4, 7, DEV)
+    outs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        loss = loss_fn(model(x, b), y, b)
+        loss.backward()
+        outs.append((float(loss), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
