@@ -45,6 +45,7 @@ struct IgemmParams {
   int unsh_C;          // unshuffle: channels of the result (= N / 8)
   int Cg;              // gated: width of one branch (channels of y / save_f / save_s)
   int n_off;           // first GEMM row of this launch (a layer's rows may be covered by two launches)
+  int grid_nblk;       // row blocks of this launch
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -83,13 +84,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave;
 
-  int tile = blockIdx.x;
+  // Workgroup -> (row block, tile): the row blocks of one tile read the same input halo, so they should run
+  // at the same time on the same XCD (own L2).  Hardware deals blockIdx round-robin over the 8 XCDs, hence
+  // ids that are congruent mod 8 are made consecutive in (tile, row block) order (bijective for any grid).
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = v % p.grid_nblk;
+  int tile = v / p.grid_nblk;
   const int tix = tile % p.ntx;
   tile /= p.ntx;
   const int tiy = tile % p.nty;
   const int tiz = tile / p.nty;
-  const int nblk = blockIdx.y;
-  const int b = blockIdx.z;
+  const int b = blockIdx.y;
   const int oz0 = tiz * TZ, oy0 = tiy * TY, ox0 = tix * 32;
   const int gz0 = oz0 * S_IN + LO, gy0 = oy0 * S_IN + LO, gx0 = ox0 * S_IN + LO;
   const long long IZYX = (long long)p.IZ * p.IY * p.IX;
@@ -535,8 +545,9 @@ int launch_one(IgemmParams& p, int B, int nblk, hipStream_t st) {
     SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  dim3 grid(p.ntz * p.nty * p.ntx, nblk, B);
-  SR3D_CHECK(grid.y <= 65535 && grid.z <= 65535, SR3D_E_ARG, "igemm: grid too large");
+  p.grid_nblk = nblk;
+  SR3D_CHECK((long long)p.ntz * p.nty * p.ntx * nblk < (1ll << 31) && B <= 65535, SR3D_E_ARG, "igemm: grid too large");
+  dim3 grid(p.ntz * p.nty * p.ntx * nblk, B, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
