@@ -116,45 +116,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
   // LDS read bases: A = dY[n = lane&31][v + (lane>>5)], B = X[column = lane&31][pos + (lane>>5)*S]
-  // where a column is a (channel, tap) pair: its halo offset is fixed for the whole kernel
+  // where a column is a (channel, tap) pair.  The three input planes of a tile live in three LDS slots
+  // that ROTATE from tile to tile (z is the fastest tile index): only the S_IN new planes are loaded per
+  // tile, the other 3 - S_IN are re-used in place.  b_base holds everything of a column's offset except
+  // its plane, kzsel its kz; the plane offset is added per tile.
   const int a_base = (wn * 32 + (lane & 31)) * PV + (lane >> 5);
-  int b_base[CTW];
+  int b_base[CTW], kzsel[CTW];
 #pragma unroll
   for (int t = 0; t < CTW; t++) {
     int j = j_begin + (wc * CTW + t) * 32 + (lane & 31);
     j = j < p.J ? j : p.J - 1;  // padded columns read something valid; they are never stored
     const int c = j / 27, tap = j - c * 27;
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    b_base[t] = (c - c_lo) * PH + (lane >> 5) * S_IN + kz * PZ + ky * RW + kx + 3;
+    b_base[t] = (c - c_lo) * PH + (lane >> 5) * S_IN + ky * RW + kx + 3;
+    kzsel[t] = kz;
   }
 
   constexpr int NT = 512;
-  // Input image staging: wave w owns channels w, w+8, ... of the block (channel = wave-uniform, so its
-  // global base pointer is scalar arithmetic); a channel's CHQ float4 pieces go to lanes (NJ per lane).
-  // Everything that depends only on the lane is computed here, once.
+  // Input staging: wave w owns channels w, w+8, ... of the block (channel = wave-uniform, so its global base
+  // pointer is scalar arithmetic); one plane of a channel is HY rows x RQ float4 = PLQ pieces <= 64 lanes.
   constexpr int CPW = (NCH + 7) / 8;        // channels per wave
-  constexpr int NJ = (CHQ + 63) / 64;       // float4 pieces per lane and channel
+  constexpr int PLQ = HY * RQ;              // float4 pieces per plane and channel
+  static_assert(PLQ <= 64, "one plane of one channel must fit one wave instruction");
+  constexpr int NEWP = S_IN;                // new planes per tile in steady state
   constexpr int PER = (ROWS * VT) / (4 * NT);  // float4 pieces of the dY tile per thread
   static_assert((ROWS * VT) % (4 * NT) == 0, "dY tile must split into float4 per thread");
-  int pz_[NJ], py_[NJ], pq_[NJ], rel_[NJ], ldso_[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int r1 = lane + 64 * j;
-    const int hz = r1 / (HY * RQ), r2 = r1 - hz * (HY * RQ);
-    const int hy = r2 / RQ, q = r2 - hy * RQ;
-    pz_[j] = r1 < CHQ ? hz : -100000;  // an out-of-range plane marks a lane without a piece
-    py_[j] = hy, pq_[j] = q;
-    rel_[j] = (hz * p.IY + hy) * p.IX + 4 * q;
-    ldso_[j] = hz * PZ + hy * RW + 4 * q;
-  }
-  f32x4 vx[CPW][NJ] = {};
+  const int l_hy = lane / RQ, l_q = lane - l_hy * RQ;   // this lane's piece of a plane
+  const bool l_on = lane < PLQ;
+  const int l_rel = l_hy * p.IX + 4 * l_q;              // offset inside a plane (floats)
+  const int l_lds = l_hy * RW + 4 * l_q;
+  f32x4 vx[NEWP][CPW] = {};
   f32x4 vd[PER] = {};
 
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
   if (t_end > p.ntiles) t_end = p.ntiles;
 
-  // coordinates of the next tile to load: decomposed once (64-bit divisions are ~200 scalar
+  // coordinates of the next tile to prefetch: decomposed once (64-bit divisions are ~200 scalar
   // instructions each), then advanced incrementally (z fastest, then x, y, sample)
   int n_oz, n_tix, n_tiy, n_b;
   {
@@ -166,18 +164,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
     n_tiy = (int)(r % p.nty);
     n_b = (int)(r / p.nty);
   }
-
-  // ---- prefetch of the NEXT tile, cut into pieces that are issued between the MFMA groups of the current
-  // tile (a burst of 12 x 1 KiB loads per wave stalls the wave at the memory pipeline's issue queue for
-  // microseconds; two loads every other k-step pair are accepted at once).
-  int c_b, c_oz, c_oy0, c_ox0, c_off0;   // context of the tile being prefetched
-  bool c_ok[NJ];
-  int c_voff[NJ];
+  int c_b = 0, c_oz = 0, c_oy0 = 0, c_ox0 = 0;   // tile whose data is (being) prefetched into vx / vd
+  bool c_rowok = false;
+  int c_rowoff = 0;
 
   auto prep_next = [&]() {
     c_oz = n_oz, c_b = n_b;
     c_oy0 = n_tiy * TY, c_ox0 = n_tix * 32;
-    if (p.dbg & 4) c_oz = 1 + (blockIdx.x & 7), c_oy0 = 2 * TY, c_ox0 = 32, c_b = 0;  // timing experiment: always the same few tiles
     if (++n_oz == p.OZ) {
       n_oz = 0;
       if (++n_tix == p.ntx) {
@@ -185,40 +178,46 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
         if (++n_tiy == p.nty) n_tiy = 0, ++n_b;
       }
     }
-    const int gz0 = c_oz * S_IN - 1, gy0 = c_oy0 * S_IN - 1, xs0 = c_ox0 * S_IN - 4;
-    c_off0 = (gz0 * p.IY + gy0) * p.IX + xs0;
+    const int gy = c_oy0 * S_IN - 1 + l_hy, xs = c_ox0 * S_IN - 4 + 4 * l_q;
+    c_rowok = l_on && (unsigned)gy < (unsigned)p.IY;
+    if (VEC) c_rowok = c_rowok && xs >= 0 && xs + 3 < p.IX;
+    c_rowoff = (c_oy0 * S_IN - 1) * p.IX + c_ox0 * S_IN - 4 + l_rel;   // + gz * IY * IX
+  };
+
+  // issue the loads of input plane `gz` (all channels of this wave) of the prefetch tile into vx[slot]
+  auto load_plane = [&](f32x4 (&dst)[CPW], const int gz) {
+    const bool zok = (unsigned)gz < (unsigned)p.IZ;
+    const int off = gz * p.IY * p.IX + c_rowoff;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int xs = xs0 + 4 * pq_[j];
-      c_ok[j] = (unsigned)(gz0 + pz_[j]) < (unsigned)p.IZ && (unsigned)(gy0 + py_[j]) < (unsigned)p.IY;
-      if (VEC) c_ok[j] = c_ok[j] && xs >= 0 && xs + 3 < p.IX;
-      c_voff[j] = c_off0 + rel_[j];
+    for (int k = 0; k < CPW; k++) {
+      const int cl = wave + 8 * k;     // wave-uniform
+      const int gc = c_lo + cl;
+      gfloat_p base = nullptr;
+      if (cl < NCH && gc < p.Cin && zok && !(p.dbg & 1)) {
+        const int si = cat_find(p.x, gc);
+        base = (gfloat_p)cat_ptr(p.x, si) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (base != nullptr && c_rowok) {
+        if (VEC) {
+          v = *(const __attribute__((address_space(1))) f32x4*)(base + off);
+        } else {
+          const int xs = c_ox0 * S_IN - 4 + 4 * l_q;
+          if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = base[off + 0];
+          if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = base[off + 1];
+          if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = base[off + 2];
+          if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = base[off + 3];
+        }
+      }
+      dst[k] = v;
     }
   };
 
-  auto load_x = [&](const int k) {   // piece k: channel wave + 8k of the block
-    const int cl = wave + 8 * k;     // wave-uniform
-    const int gc = c_lo + cl;
-    gfloat_p base = nullptr;
-    if (cl < NCH && gc < p.Cin && !(p.dbg & 1)) {
-      const int si = cat_find(p.x, gc);
-      base = (gfloat_p)cat_ptr(p.x, si) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
-    }
+  auto store_plane = [&](const f32x4 (&src)[CPW], const int slot) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (base != nullptr && c_ok[j]) {
-        if (VEC) {
-          v = *(const __attribute__((address_space(1))) f32x4*)(base + c_voff[j]);
-        } else {
-          const int xs = c_ox0 * S_IN - 4 + 4 * pq_[j];
-          if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = base[c_voff[j] + 0];
-          if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = base[c_voff[j] + 1];
-          if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = base[c_voff[j] + 2];
-          if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = base[c_voff[j] + 3];
-        }
-      }
-      vx[k][j] = v;
+    for (int k = 0; k < CPW; k++) {
+      const int cl = wave + 8 * k;
+      if (cl < NCH && l_on) *reinterpret_cast<f32x4*>(&Xs[cl * PH + slot * PZ + l_lds]) = src[k];
     }
   };
 
@@ -246,30 +245,39 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   };
 
   __syncthreads();  // pointer tables are visible
+  bool fresh = true;   // the tile about to be stored starts a new z column: all three planes are new
+  int s0 = 0;          // LDS slot of plane kz = 0 of the current tile
   if (t_begin < t_end) {
     prep_next();
-#pragma unroll
-    for (int k = 0; k < CPW; k++) load_x(k);
     load_dy();
   }
 
   constexpr int KS = TY * 16;        // k-steps (2 voxels each) per tile
   constexpr int NG = KS / 2;         // MFMA groups (2 k-steps each)
-  static_assert(NG >= CPW + 1, "not enough MFMA groups to spread the prefetch over");
-  constexpr int GSTEP = NG / (CPW + 1);  // a prefetch piece after every GSTEP-th group
+  static_assert(NG >= NEWP + 1, "not enough MFMA groups to spread the prefetch over");
+  constexpr int GSTEP = NG / (NEWP + 1);  // a prefetch piece after every GSTEP-th group
 
   for (long long tile = t_begin; tile < t_end; tile++) {
     __syncthreads();  // previous tile fully consumed
-    if (!(p.dbg & 2) || tile == t_begin) {
+    if (fresh) {
+      // start of a z column (or of this workgroup's range): fill all three slots, synchronously
+      s0 = 0;
 #pragma unroll
-      for (int k = 0; k < CPW; k++) {
-        const int cl = wave + 8 * k;
-        if (cl < NCH) {
+      for (int k0 = 0; k0 < 3; k0 += NEWP) {
 #pragma unroll
-          for (int j = 0; j < NJ; j++)
-            if (pz_[j] >= 0) *reinterpret_cast<f32x4*>(&Xs[cl * PH + ldso_[j]]) = vx[k][j];
-        }
+        for (int q = 0; q < NEWP; q++)
+          if (k0 + q < 3) load_plane(vx[q], c_oz * S_IN - 1 + k0 + q);
+#pragma unroll
+        for (int q = 0; q < NEWP; q++)
+          if (k0 + q < 3) store_plane(vx[q], k0 + q);
       }
+    } else if (!(p.dbg & 2)) {
+      // steady state: the NEWP new planes (prefetched during the previous tile) replace the oldest ones
+      s0 = (s0 + NEWP) % 3;
+#pragma unroll
+      for (int q = 0; q < NEWP; q++) store_plane(vx[q], (s0 + 3 - NEWP + q) % 3);
+    }
+    if (!(p.dbg & 2) || tile == t_begin) {
 #pragma unroll
       for (int i = 0; i < PER; i++) {
         const int e = (tid + i * NT) * 4;
@@ -279,15 +287,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
     }
     __syncthreads();
     const bool more = tile + 1 < t_end;
-    if (more) prep_next();
+    if (more) {
+      prep_next();
+      fresh = c_oz == 0;   // the next tile starts a new column: its planes are loaded at its own store phase
+    }
+
+    // per-lane plane offsets of this tile's three slots
+    int boff[CTW];
+    {
+      const int po0 = s0 * PZ, po1 = ((s0 + 1) % 3) * PZ, po2 = ((s0 + 2) % 3) * PZ;
+#pragma unroll
+      for (int t = 0; t < CTW; t++) boff[t] = b_base[t] + (kzsel[t] == 0 ? po0 : (kzsel[t] == 1 ? po1 : po2));
+    }
 
     // MFMA loop, fragments double-buffered in registers.  The sched_barriers keep the LDS reads of k-step
-    // s+1 ABOVE the MFMAs of k-step s (hipcc otherwise sinks them to just before their use).
+    // s+1 ABOVE the MFMAs of k-step s (hipcc otherwise sinks them to just before their use).  The prefetch
+    // of the next tile is cut into pieces issued between MFMA groups.
     auto frag = [&](int s, float& a, float (&bv)[CTW]) {
       const int row = s >> 4, xx = (s & 15) * 2;
       a = Ds[a_base + row * 32 + xx];
 #pragma unroll
-      for (int t = 0; t < CTW; t++) bv[t] = Xs[b_base[t] + (row * S_IN) * RW + xx * S_IN];
+      for (int t = 0; t < CTW; t++) bv[t] = Xs[boff[t] + (row * S_IN) * RW + xx * S_IN];
     };
     if (!(p.dbg & 8)) {
       float a0, a1, b0[CTW], b1[CTW];
@@ -307,15 +327,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (more && g % GSTEP == 0) {
           const int piece = g / GSTEP;
-          if (piece < CPW)
-            load_x(piece);
-          else if (piece == CPW)
+          if (piece < NEWP) {
+            if (!fresh) load_plane(vx[piece], c_oz * S_IN - 1 + (3 - NEWP) + piece);
+          } else if (piece == NEWP) {
             load_dy();
+          }
         }
       }
     } else if (more) {
 #pragma unroll
-      for (int k = 0; k < CPW; k++) load_x(k);
+      for (int q = 0; q < NEWP; q++)
+        if (!fresh) load_plane(vx[q], c_oz * S_IN - 1 + (3 - NEWP) + q);
       load_dy();
     }
   }
