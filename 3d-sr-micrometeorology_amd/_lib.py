@@ -53,6 +53,7 @@ SYMBOLS = {
     "sr3d_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
+    "sr3d_mixed_div_grad_l2_bwd": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
     "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),
     "sr3d_profile_enable": (_I, [_I]),
     "sr3d_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

@@ -90,6 +90,7 @@ struct MixParams {
   float* sums;       // 4 floats: sum d^2, grd numerator, div numerator, sum M
   float* terms;      // out: mse, grd, div, total
   float* dldp;
+  const float* wts;  // device, 3 floats: d(result)/d(mse, grd, div); null = (1, w_g, w_d)
 };
 
 __device__ __forceinline__ float cdiff(float hi, float lo, float w) { return hi * w + lo * (-w); }
@@ -212,11 +213,15 @@ __global__ __launch_bounds__(kThreads) void mix_pass2_kernel(const MixParams q) 
   const long long total = (long long)q.B * zyx;
   const long long sy = q.X, sz = (long long)q.Y * q.X;
   const float sumM = q.sums[3];
-  const float c_mse = 2.f / (4.f * (float)q.B * (float)zyx);
-  const float c_grd = q.w_g != 0.f ? q.w_g / (4.f * sumM + 1.f) : 0.f;
+  // weights of the three terms in the scalar whose gradient is wanted (autograd may ask for any mix)
+  const float u_mse = q.wts ? q.wts[0] : 1.f;
+  const float u_grd = q.w_g != 0.f ? (q.wts ? q.wts[1] : q.w_g) : 0.f;   // a skipped term has no gradient
+  const float u_div = q.w_d != 0.f ? (q.wts ? q.wts[2] : q.w_d) : 0.f;
+  const float c_mse = u_mse * 2.f / (4.f * (float)q.B * (float)zyx);
+  const float c_grd = u_grd / (4.f * sumM + 1.f);
   const float w5 = 1.f / (2.f * q.delta);
   const float k = q.delta / q.mean_scale;
-  const float c_div = q.w_d != 0.f ? q.w_d / (sumM + 1.f) * (-2.f * k * w5) : 0.f;
+  const float c_div = u_div / (sumM + 1.f) * (-2.f * k * w5);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     long long r = i;
@@ -328,6 +333,29 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
     hipLaunchKernelGGL(mix_pass2_kernel, dim3(grid_for(vox, 1)), dim3(kThreads), 0, (hipStream_t)stream, q);
     SR3D_HIP(hipGetLastError());
   }
+  return SR3D_OK;
+}
+
+/* gradient of  wts[0]*mse + wts[1]*grd_mse + wts[2]*div_mse  w.r.t. p, from the fields a previous
+ * sr3d_mixed_div_grad_l2_fwd_bwd call (same arguments, same workspace) left in the workspace */
+int sr3d_mixed_div_grad_l2_bwd(const void* p, const void* t, int B, int Z, int Y, int X, const float scales[3],
+                               float delta_meter, float w_g, float w_d, const void* term_weights, void* dLdp,
+                               void* workspace, void* stream) {
+  SR3D_CHECK(p && t && dLdp && workspace && scales && term_weights, SR3D_E_ARG, "mixed_loss_bwd: null pointer");
+  SR3D_CHECK(B > 0 && Z >= 3 && Y >= 3 && X >= 3 && delta_meter > 0.f, SR3D_E_ARG, "mixed_loss_bwd: bad argument");
+  const long long vox = (long long)B * Z * Y * X;
+  MixParams q{};
+  q.p = (const float*)p, q.t = (const float*)t;
+  q.B = B, q.Z = Z, q.Y = Y, q.X = X;
+  q.s[0] = scales[0], q.s[1] = scales[1], q.s[2] = scales[2];
+  q.w_g = w_g, q.w_d = w_d, q.delta = delta_meter;
+  q.mean_scale = (float)(((double)scales[0] + (double)scales[1] + (double)scales[2]) / 3.0);
+  float* ws = (float*)workspace;
+  q.fieldM = ws, q.fieldE = ws + vox;
+  q.part = ws + 2 * vox, q.sums = ws + 2 * vox + 4 * kMaxBlocks;
+  q.dldp = (float*)dLdp, q.wts = (const float*)term_weights;
+  hipLaunchKernelGGL(mix_pass2_kernel, dim3(grid_for(vox, 1)), dim3(kThreads), 0, (hipStream_t)stream, q);
+  SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 

@@ -253,8 +253,10 @@ class L1LossFn(torch.autograd.Function):
 
 
 class MixedLossFn(torch.autograd.Function):
-    """MixedDivergenceGradientL2Loss terms + dL/dp (reference loss_maker.py:387-450).
-    Returns a 4-vector (mse, grd_mse, div_mse, total); only ``total`` carries a gradient."""
+    """MixedDivergenceGradientL2Loss (reference loss_maker.py:387-450).
+    Returns a 4-vector (mse, grd_mse, div_mse, total).  Every component is differentiable (GradNorm takes
+    per-term gradients, gradnorm.py:95-100): backward runs ONE adjoint-stencil kernel for whatever linear
+    combination of the terms autograd asks for; the combination weights stay on the device."""
 
     @staticmethod
     def forward(ctx, p, t, b, scales, delta, w_g, w_d):
@@ -262,23 +264,30 @@ class MixedLossFn(torch.autograd.Function):
         B, c, Z, Y, X = p.shape
         if c != 4 or t.shape != p.shape or tuple(b.shape) != (B, 1, Z, Y, X):
             raise ValueError("mixed loss expects p,t: (B,4,Z,Y,X) and masks: (B,1,Z,Y,X)")
-        need = ctx.needs_input_grad[0]
         ws = torch.empty(L.lib.sr3d_loss_workspace_bytes(B, Z, Y, X) // 4, dtype=torch.float32, device=p.device)
         terms = _empty((4,), p)
-        g = torch.empty_like(p) if need else None
         sc = (C.c_float * 3)(*[float(s) for s in scales])
         L.check(L.lib.sr3d_mixed_div_grad_l2_fwd_bwd(L.dev_ptr(p), L.dev_ptr(t), L.dev_ptr(b), B, Z, Y, X, sc,
                                                      float(delta), float(w_g), float(w_d), L.dev_ptr(terms),
-                                                     L.dev_ptr(g), L.dev_ptr(ws), L.stream_ptr()),
+                                                     None, L.dev_ptr(ws), L.stream_ptr()),
                 "sr3d_mixed_div_grad_l2_fwd_bwd")
-        ctx.save_for_backward(g)
+        ctx.args = (B, Z, Y, X, [float(s) for s in scales], float(delta), float(w_g), float(w_d))
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(p, t, ws)
         return terms
 
     @staticmethod
     def backward(ctx, gterms):
-        (g,) = ctx.saved_tensors
-        # d(total)/dp is what the kernel produced; the three individual terms are reported without gradient
-        return g * gterms[3], None, None, None, None, None, None
+        p, t, ws = ctx.saved_tensors
+        B, Z, Y, X, scales, delta, w_g, w_d = ctx.args
+        g = gterms.to(torch.float32)
+        wts = torch.stack([g[0] + g[3], g[1] + g[3] * w_g, g[2] + g[3] * w_d]).contiguous()
+        dp = torch.empty_like(p)
+        sc = (C.c_float * 3)(*scales)
+        L.check(L.lib.sr3d_mixed_div_grad_l2_bwd(L.dev_ptr(p), L.dev_ptr(t), B, Z, Y, X, sc, delta, w_g, w_d,
+                                                 L.dev_ptr(wts), L.dev_ptr(dp), L.dev_ptr(ws), L.stream_ptr()),
+                "sr3d_mixed_div_grad_l2_bwd")
+        return dp, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------- optimizer

@@ -76,8 +76,7 @@ class MixedDivergenceGradientL2Loss(nn.Module):
 
     def calc_loss_terms(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
         """(mse, grd_mse, div_mse); skipped terms are the float 0.0 as in loss_maker.py:399-413.
-        The per-term values are reported without autograd history (GradNorm, which needs per-term
-        gradients, is a later scope row: SURVEY.md 8(f) N3)."""
+        Each returned tensor is differentiable on its own (GradNorm: optim_helper.py:167-175)."""
         t = self._terms(predicts, targets, masks)
         grd = t[1] if self.weight_gradient_loss != 0.0 else 0.0
         div = t[2] if self.weight_divergence_loss != 0.0 else 0.0

@@ -141,6 +141,13 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
                                    const float scales[3], float delta_meter, float w_g, float w_d,
                                    void* terms_out, void* dLdp, void* workspace, void* stream);
 
+/* dLdp = d(wts[0]*mse + wts[1]*grd_mse + wts[2]*div_mse)/dp with the three weights read from DEVICE memory
+ * (autograd / GradNorm, gradnorm.py:95-100, differentiate individual terms); reuses the workspace a previous
+ * sr3d_mixed_div_grad_l2_fwd_bwd call with the same arguments filled. */
+int sr3d_mixed_div_grad_l2_bwd(const void* p, const void* t, int B, int Z, int Y, int X, const float scales[3],
+                               float delta_meter, float w_g, float w_d, const void* term_weights, void* dLdp,
+                               void* workspace, void* stream);
+
 /* ---- optimizer -------------------------------------------------------------- */
 /* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based.  The
  * hyper-parameters are doubles, as in torch (1 - beta2 must be formed in double to match it). */
