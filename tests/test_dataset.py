@@ -1,0 +1,55 @@
+"""The sample pipeline in front of the hot path vs golden vectors produced by the
+reference's own DatasetWithoutAligningResolution on the same synthetic files.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from data_fixture import CASES, write_synthetic_tree
+from helpers import load_golden
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    return write_synthetic_tree(tmp_path_factory.mktemp("data"))
+
+
+def test_split_is_chronological(tree):
+    import sr3d_amd
+    from sr3d_amd.src.dataloader import get_all_new_lr_data_dir_paths, split_into_train_valid_test_dirs
+    g = load_golden("dataset.npz")
+    dirs = get_all_new_lr_data_dir_paths(tree)
+    sp = split_into_train_valid_test_dirs(dirs, [0.6, 0.2, 0.2])
+    assert [len(sp[k]) for k in ("train", "valid", "test")] == list(g["split_sizes"])
+    assert [os.path.basename(str(sp[k][0])) for k in ("train", "valid", "test")] == list(g["split_first"])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_samples_match_reference(tree, case):
+    import sr3d_amd
+    from sr3d_amd.src.dataloader import get_all_new_lr_data_dir_paths
+    from sr3d_amd.src.dataset import DatasetWithoutAligningResolution
+    g = load_golden("dataset.npz")
+    ds = DatasetWithoutAligningResolution(data_dirs=get_all_new_lr_data_dir_paths(tree),
+                                          hr_3d_build_path=tree / "10" / "hr_is_in_build.npy", **CASES[case])
+    assert len(ds) == int(g[f"{case}/len"])
+    for idx in (0, 3):
+        torch.manual_seed(100 + idx)   # same seed -> same random crop as the reference drew
+        lr, b, hr = ds[idx]
+        for name, t in (("lr", lr), ("b", b), ("hr", hr)):
+            ref = g[f"{case}/{idx}/{name}"]
+            assert tuple(t.shape) == ref.shape, (name, t.shape, ref.shape)
+            assert np.array_equal(t.numpy(), ref, equal_nan=True), (case, idx, name)
+
+
+def test_dataloaders_yield_batches_the_loops_expect(tree):
+    import sr3d_amd
+    from sr3d_amd.src.dataloader import get_all_new_lr_data_dir_paths, make_dataloaders, split_into_train_valid_test_dirs
+    dirs = get_all_new_lr_data_dir_paths(tree)
+    loaders, samplers = make_dataloaders(split_into_train_valid_test_dirs(dirs, [0.6, 0.2, 0.2]),
+                                         tree / "10" / "hr_is_in_build.npy", batch_size=2, num_workers=0,
+                                         **{k: v for k, v in CASES["crop"].items()})
+    Xs, bs, ys = next(iter(loaders["train"]))
+    assert tuple(Xs.shape) == (2, 4, 2, 2, 3) and tuple(bs.shape) == (2, 8, 8, 12) and tuple(ys.shape) == (2, 4, 8, 8, 12)
+    assert samplers == {}
