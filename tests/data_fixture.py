@@ -15,14 +15,14 @@ CASES = {
 }
 
 
-def write_synthetic_tree(tmp) -> pathlib.Path:
+def write_synthetic_tree(tmp, HR=HR, days=5) -> pathlib.Path:
     rng = np.random.default_rng(2024)
     root = pathlib.Path(tmp) / "DL_data"
     build = (rng.random((1,) + HR) < 0.15).astype(np.float32)
-    build[:, 4:] = 0  # buildings only near the ground
+    build[:, HR[0] // 2:] = 0  # buildings only near the ground
     (root / "10").mkdir(parents=True)
     np.save(root / "10" / "hr_is_in_build.npy", build)
-    for day in range(5):
+    for day in range(days):
         d = root / "10" / f"2013080{day + 1}"
         d.mkdir()
         for t in range(2):
