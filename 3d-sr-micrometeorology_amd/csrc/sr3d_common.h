@@ -25,6 +25,8 @@ struct ChanCat {
 
 void sr3d_set_error(const char* fmt, ...);
 
+
+
 #define SR3D_CHECK(cond, code, ...)        \
   do {                                     \
     if (!(cond)) {                         \
@@ -41,6 +43,34 @@ void sr3d_set_error(const char* fmt, ...);
       return SR3D_E_HIP;                                                      \
     }                                                                         \
   } while (0)
+
+// conv epilogues shared by the direct (sr3d_igemm.hip) and Winograd (sr3d_wino.hip) kernels
+enum { SR3D_EPI_PLAIN = 0, SR3D_EPI_GATED = 1, SR3D_EPI_UNSHUFFLE = 2 };
+
+// launch description of the Winograd stride-1 conv (sr3d_wino.hip); filled by the entry points in sr3d_igemm.hip
+struct SrWinoParams {
+  ChanCat in;          // K side (virtual concat)
+  int K;               // input channels
+  int Z, Y, X;         // grid (stride 1: input grid = output grid)
+  int ntz, nty, ntx, nblk, nchunks;   // set by sr3d_wino_launch
+  const float* up;     // transformed + packed weights
+  int N;               // GEMM rows (gated: 32 per 16 channels)
+  int n_off;
+  int epi, act;
+  const float* bias;
+  const float* bias2;
+  ChanCat out;         // plain epilogue destinations
+  float* y;
+  float* save_f;
+  float* save_s;
+  int TZ_, TY_, TX_;   // destination grid (2x for the unshuffle epilogue)
+  int unsh_C, Cg;
+};
+bool sr3d_wino_enabled();
+size_t sr3d_wino_image_floats(int rows, int K);
+int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
+                   const int* cbeg, float* image, hipStream_t st);
+int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st);
 
 // per-kernel HIP-event timing (off unless sr3d_profile_enable(1)); ids are SR3D_PROF_*
 bool sr3d_prof_active();

@@ -406,6 +406,12 @@ inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD && d->Cout <= 4 && d->stride == 1;
 }
 
+// stride-1 convolutions (forward and input gradient) run on the Winograd kernel (sr3d_wino.hip)
+inline bool use_wino(const sr3d_conv_desc_t* d) { return d->stride == 1 && sr3d_wino_enabled(); }
+inline int wino_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
+  return kind == SR3D_PACK_FWD_GATED ? 32 * ((d->Cout + 15) / 16) : d->Cout;
+}
+
 // --------------------------------------------------------------------- packing
 // Packed image of one launch region: [nblk][chunk][tap][KC][BN] with BN = 32*RT.
 // A layer's rows are covered by (U / 4) blocks of 128 rows plus one block with the
@@ -646,6 +652,7 @@ extern "C" {
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
+  if (use_wino(d)) return sr3d_wino_image_floats(wino_fwd_rows(d, kind), d->Cin) * 4;
   return image_floats(ceil_div(fwd_rows(d, kind), 32), ceil_div(d->Cin, kKC), 27) * 4;
 }
 
@@ -661,6 +668,9 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
   }
+  if (use_wino(d))
+    return sr3d_wino_pack(kind, d->Cout, d->Cin, wino_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
+                          (const float*)w_gate, nullptr, nullptr, (float*)w_packed, (hipStream_t)stream);
   PackParams p{};
   p.w1 = (const float*)w_feat, p.w2 = (const float*)w_gate;
   p.Cout = d->Cout, p.Cin = d->Cin, p.kind = kind, p.K = d->Cin, p.N = fwd_rows(d, kind);
@@ -686,6 +696,25 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3(q.ntz * q.nty * q.ntx, d->B), dim3(256), 0, (hipStream_t)stream, q);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
+  }
+  if (use_wino(d)) {
+    SrWinoParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
+    for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X, q.N = d->Cout;
+    q.up = (const float*)w_packed, q.act = act, q.bias = (const float*)bias;
+    if (unshuffle) {
+      SR3D_CHECK(d->Cout % 8 == 0 && bias != nullptr, SR3D_E_ARG,
+                 "conv3d_fwd: unshuffle needs Cout %% 8 == 0 and a bias (Cout = %d)", d->Cout);
+      q.epi = SR3D_EPI_UNSHUFFLE, q.y = (float*)y, q.unsh_C = d->Cout / 8;
+      q.TZ_ = 2 * d->Z, q.TY_ = 2 * d->Y, q.TX_ = 2 * d->X;
+    } else {
+      q.epi = SR3D_EPI_PLAIN;
+      sr3d_slice_t ys{y, d->Cout};
+      if (int rc = sr3d_make_cat(&ys, 1, (long long)d->Z * d->Y * d->X, d->Cout, &q.out, "y")) return rc;
+      q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    }
+    return sr3d_wino_launch(q, d->B, (hipStream_t)stream);
   }
   IgemmParams p{};
   p.N = d->Cout;
@@ -714,6 +743,18 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "gated_conv3d_fwd: null pointer");
   SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_conv3d_fwd: unknown activation %d", act);
+  if (use_wino(d)) {
+    SrWinoParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
+    for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.N = wino_fwd_rows(d, SR3D_PACK_FWD_GATED), q.Cg = d->Cout;
+    q.up = (const float*)w_packed, q.act = act, q.epi = SR3D_EPI_GATED;
+    q.bias = (const float*)bias_f, q.bias2 = (const float*)bias_g;
+    q.y = (float*)y, q.save_f = (float*)save_f, q.save_s = (float*)save_s;
+    q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    return sr3d_wino_launch(q, d->B, (hipStream_t)stream);
+  }
   IgemmParams p{};
   p.epi = EPI_GATED;
   p.act = act;
@@ -735,7 +776,9 @@ static int bwd_rows(const sr3d_slice_t* dx_dsts, int n_dst) {
 size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy) {
   if (check_desc(d) != SR3D_OK || (n_dy != 1 && n_dy != 2)) return 0;
   // upper bound: every input channel needs a gradient; stride 2 stores the 8 parity-class images (27 taps in total)
-  return image_floats(ceil_div(d->Cin, 32), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
+  const size_t direct = image_floats(ceil_div(d->Cin, 32), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
+  const size_t wino = use_wino(d) ? sr3d_wino_image_floats(d->Cin, n_dy * d->Cout) * 4 : 0;
+  return direct > wino ? direct : wino;
 }
 
 int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
@@ -786,6 +829,15 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   pk.K = K, pk.N = rows, pk.nchunks = p.nchunks;
   float* image = (float*)workspace;
 
+  if (use_wino(d)) {
+    SrWinoParams q{};
+    q.in = p.in, q.out = p.out;
+    q.K = K, q.N = rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE, q.up = image;
+    if (int rc = sr3d_wino_pack(pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
+    return sr3d_wino_launch(q, d->B, st);
+  }
   if (d->stride == 1) {
     pk.ntaps = 27;
     for (int t = 0; t < 27; t++) pk.tap[t] = t;

@@ -49,7 +49,10 @@ def test_argument_errors_are_reported_not_crashes(eng):
     with pytest.raises(RuntimeError, match="failed"):
         L.check(rc, "sr3d_adam_step")
     # workspace queries are pure host arithmetic
-    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 1 * 27 * 4 * 32 * 4   # one 32-row tile
+    # stride 1 -> Winograd image [row block][chunk][kz 3][xi 16][4 ch][32 rows]; stride 2 -> direct [..][27 taps][4][32]
+    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 1 * 3 * 16 * 4 * 32 * 4
+    d2 = L.conv_desc(1, 4, 8, 8, 8, 8, 2)
+    assert lib.sr3d_packed_weight_bytes(C.byref(d2), L.PACK_FWD) == 1 * 1 * 27 * 4 * 32 * 4
     d4 = L.conv_desc(1, 69, 4, 8, 8, 8, 1)   # <= 4 output channels: the VALU path's [Cin][27][4] image
     assert lib.sr3d_packed_weight_bytes(C.byref(d4), L.PACK_FWD) == 69 * 27 * 4 * 4
     assert lib.sr3d_conv3d_bwd_weight_workspace_bytes(C.byref(d), 4) > 0
