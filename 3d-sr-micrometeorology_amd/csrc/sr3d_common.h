@@ -65,6 +65,7 @@ struct SrWinoParams {
   float* save_s;
   int TZ_, TY_, TX_;   // destination grid (2x for the unshuffle epilogue)
   int unsh_C, Cg;
+  int pair_aligned;    // every destination pointer is 8-byte aligned
 };
 bool sr3d_wino_enabled();
 size_t sr3d_wino_image_floats(int rows, int K);
