@@ -72,6 +72,10 @@ size_t sr3d_wino_image_floats(int rows, int K);
 int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                    const int* cbeg, float* image, hipStream_t st);
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st);
+// Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
+size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total);
+int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, float* dw, float* ws,
+                    hipStream_t st);
 
 // per-kernel HIP-event timing (off unless sr3d_profile_enable(1)); ids are SR3D_PROF_*
 bool sr3d_prof_active();

@@ -496,6 +496,14 @@ SmallNPlan smalln_plan(const sr3d_conv_desc_t* d) {
   return pl;
 }
 
+// Winograd-domain weight gradient (sr3d_wino_wgrad.hip): correct (parity-tested with SR3D_WINOGRAD_WGRAD=1) but
+// its per-strip transform/staging overhead still outweighs the 2.25x MFMA saving (75 vs 100 TF-equivalent on
+// MI355X), so the direct kernel stays the default until the strips are made larger.
+inline bool use_wino_wgrad(const sr3d_conv_desc_t* d, int n_total) {
+  static const bool on = getenv("SR3D_WINOGRAD_WGRAD") ? atoi(getenv("SR3D_WINOGRAD_WGRAD")) != 0 : false;
+  return on && sr3d_wino_enabled() && d->stride == 1 && d->Cin >= 16 && n_total > 4;
+}
+
 inline bool use_smalln(const sr3d_conv_desc_t* d, int n_total, int n_dy) {
   return n_total <= 4 && n_dy == 1 && d->stride == 1 && d->Cin <= 65535;
 }
@@ -626,6 +634,7 @@ extern "C" {
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total) {
   if (!d || d->Cin <= 0 || n_total <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
   if (use_smalln(d, n_total, 1)) return (size_t)smalln_plan(d).S * d->Cin * 108 * 4;
+  if (use_wino_wgrad(d, n_total)) return sr3d_wino_wgrad_ws_bytes(d, n_total);
   const Plan pl = make_plan(d, n_total);
   return (size_t)pl.S * pl.Npad * pl.Jpad * 4;
 }
@@ -664,6 +673,16 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
                        (const float*)workspace, (float*)dw, sp.S, n_total, d->Cin);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
+  }
+  if (use_wino_wgrad(d, n_total)) {
+    SR3D_CHECK(workspace_bytes >= sr3d_wino_wgrad_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
+               "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+    ChanCat xc, dc;
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
+    if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
+    for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+    return sr3d_wino_wgrad(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream);
   }
   const Plan pl = make_plan(d, n_total);
   SR3D_CHECK(workspace_bytes >= (size_t)pl.S * pl.Npad * pl.Jpad * 4, SR3D_E_WORKSPACE,
