@@ -240,3 +240,17 @@ def test_errors_are_loud(eng):
         eng.ops.conv3d_act([x.to(DEV)], torch.rand(2, 4, 3, 3, 3).to(DEV), None)
     with pytest.raises(NotImplementedError):
         eng.model.custom_conv.MyConvWithAct2(3, 2, 3, padding=1, conv_mode="p_conv")
+
+
+@pytest.mark.parametrize("env", [{"SR3D_WINOGRAD": "0"}, {"SR3D_WINOGRAD_WGRAD": "1"}])
+def test_alternative_kernel_paths_in_subprocess(env):
+    """the direct stride-1 kernels (SR3D_WINOGRAD=0) and the experimental Winograd weight gradient are selected
+    once per process from the environment: run the conv / model parity tests again under each setting"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "conv_wrappers or split_sources or upblock or full_model or odd_shapes or fullwidth"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
