@@ -32,6 +32,9 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic work per HR voxel per training step, default.yml widths
 FLOP_PER_VOXEL = 8_486_693
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# HBM traffic of the dominant kernel family per launch, from separate rocprofv3 --pmc passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass; FETCH_SIZE doubled as the guide prescribes for gfx950)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
 
 DEFAULT_CONFIG = {
     "data": {"stds": [8.40, 14.40, 21.60, 7.00]},
@@ -187,6 +190,15 @@ def main():
         value = vox_per_step * args.steps / elapsed
         dom = prof["igemm_s1"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        wino = os.environ.get("SR3D_WINOGRAD", "1") != "0"
+        traffic = None
+        if os.path.exists(TRAFFIC_JSON) and args.batch == 1 and args.loss == "l1" and wino:
+            t = json.load(open(TRAFFIC_JSON)).get("igemm_s1")
+            if t:
+                traffic = {"hbm_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"] + t["write_bytes_per_launch"],
+                           "fetch_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"],
+                           "write_bytes_per_launch": t["write_bytes_per_launch"],
+                           "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         per_kernel = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                           "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
                       for k, v in prof.items()}
@@ -210,8 +222,13 @@ def main():
                        "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "igemm_kernel<S_IN=1> (stride-1 conv forward + input gradient, fp32 MFMA 32x32x2)",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
+                                   "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)",
+                         "note": "achieved = ALGORITHMIC FLOPs of the 3x3x3 convolution (2*27*Cin*Cout per output voxel) / "
+                                 "kernel time; the Winograd kernel issues 2.25x fewer MFMA FLOPs than that "
+                                 "(executed_tflops), all in fp32",
+                         "executed_tflops": ach / (2.25 if wino else 1.0),
                          "launches_per_step": dom["launches"] / args.steps,
                          "kernel_ms_per_step": dom["ms"] / args.steps},
             "step_tflops": FLOP_PER_VOXEL * value / 1e12,
