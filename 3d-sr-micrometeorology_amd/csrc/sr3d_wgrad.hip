@@ -13,6 +13,8 @@
 // use_deterministic=True: utils.py:70-92).
 // X and dY are virtual channel concatenations (sr3d_common.h), e.g. dY =
 // [d_feat ; d_gate] of a gated layer yields dW = [dWf ; dWg] in one pass.
+#include <algorithm>
+#include <cstdint>
 #include "sr3d_common.h"
 
 #include <stdlib.h>
@@ -496,12 +498,20 @@ SmallNPlan smalln_plan(const sr3d_conv_desc_t* d) {
   return pl;
 }
 
-// Winograd-domain weight gradient (sr3d_wino_wgrad.hip): correct (parity-tested with SR3D_WINOGRAD_WGRAD=1) but
-// its per-strip transform/staging overhead still outweighs the 2.25x MFMA saving (75 vs 100 TF-equivalent on
-// MI355X), so the direct kernel stays the default until the strips are made larger.
+// Winograd-domain weight gradient (sr3d_wino_wgrad.hip) for the stride-1 layers; SR3D_WINOGRAD_WGRAD=0 selects
+// the direct kernel.  The kernel feeds dY rows in groups of 4 with float2 loads: slice widths must be multiples of
+// 4, X even and the dY pointers 8-byte aligned; anything else takes the direct kernel.
+inline bool wino_wgrad_on() {
+  static const bool on = getenv("SR3D_WINOGRAD_WGRAD") ? atoi(getenv("SR3D_WINOGRAD_WGRAD")) != 0 : true;
+  return on && sr3d_wino_enabled();
+}
 inline bool use_wino_wgrad(const sr3d_conv_desc_t* d, int n_total) {
-  static const bool on = getenv("SR3D_WINOGRAD_WGRAD") ? atoi(getenv("SR3D_WINOGRAD_WGRAD")) != 0 : false;
-  return on && sr3d_wino_enabled() && d->stride == 1 && d->Cin >= 16 && n_total > 4;
+  return wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0;
+}
+inline bool wino_wgrad_slices_ok(const sr3d_slice_t* dy_srcs, int n_dy) {
+  for (int i = 0; i < n_dy; i++)
+    if (dy_srcs[i].channels % 4 || ((uintptr_t)dy_srcs[i].ptr & 7)) return false;
+  return true;
 }
 
 inline bool use_smalln(const sr3d_conv_desc_t* d, int n_total, int n_dy) {
@@ -634,9 +644,10 @@ extern "C" {
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total) {
   if (!d || d->Cin <= 0 || n_total <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
   if (use_smalln(d, n_total, 1)) return (size_t)smalln_plan(d).S * d->Cin * 108 * 4;
-  if (use_wino_wgrad(d, n_total)) return sr3d_wino_wgrad_ws_bytes(d, n_total);
   const Plan pl = make_plan(d, n_total);
-  return (size_t)pl.S * pl.Npad * pl.Jpad * 4;
+  size_t bytes = (size_t)pl.S * pl.Npad * pl.Jpad * 4;
+  if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, sr3d_wino_wgrad_ws_bytes(d, n_total));
+  return bytes;
 }
 
 int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src,
@@ -674,7 +685,7 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
   }
-  if (use_wino_wgrad(d, n_total)) {
+  if (use_wino_wgrad(d, n_total) && wino_wgrad_slices_ok(dy_srcs, n_dy)) {
     SR3D_CHECK(workspace_bytes >= sr3d_wino_wgrad_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
                "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
     ChanCat xc, dc;

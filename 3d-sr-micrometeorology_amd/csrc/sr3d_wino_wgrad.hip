@@ -7,26 +7,38 @@
 // 16 products per tile, channel pair and kz instead of 36: 2.25x fewer MFMA issues than the direct kernel
 // (sr3d_wgrad.hip), same fp32 arithmetic.
 //
-// One 512-thread workgroup owns a 32(n) x 32(c) block of dU for all 3 x 16 (kz, xi): wave w keeps xi = 2w, 2w+1
-// for the three kz (6 accumulators).  The reduction runs over strips of 8 tiles (2 x 16 voxels of one output
-// plane), z fastest.  Per strip: the raw rows prefetched during the previous strip go to LDS, 256 threads
-// transform the ONE new input plane (c, tile) -> V (the other two planes of the 3-plane window are re-used in
-// place, rotating slots), 256 threads transform dY (n, tile) -> dM, then the MFMAs read both as plain
-// conflict-free fragments (2 LDS reads per MFMA, no transform work in the MFMA phase).
+// One 512-thread workgroup (the only one on its CU: 12 accumulator tiles per wave) owns a 64(n) x 32(c) block of
+// dU for all 3 x 16 (kz, xi): wave w keeps xi = 2w, 2w+1 for the three kz and both 32-row tiles.  The reduction
+// walks columns of the grid (8 tiles = 2 x 16 voxels of one plane, z fastest) as a stream of PLANE STEPS:
+// step s brings ONE new input plane into the Winograd domain (V slot s & 3; the other two planes of the 3-plane
+// window were transformed by steps s-1, s-2) and the dY plane of the output that step s completes (dM buffer
+// s & 1).  The step is software-pipelined so that the single workgroup of the CU never idles its MFMA pipe:
+//     iteration s:  dM(s) from registers  |  global loads of step s+1 (x plane, dY)  |
+//                   MFMAs of step s-1's output, the V transform of step s scheduled between them  |
+//                   raw x rows of step s+1 -> LDS  |  ONE barrier
+// All LDS layouts are bank-conflict-free by construction (see the pitch constants), the global base pointers are
+// wave-uniform, everything depending only on the lane is computed once per column.
 #include "sr3d_common.h"
 
 namespace {
 
 constexpr int GT = 8;                       // Winograd tiles per strip (1 tile row x 8 tile columns)
 constexpr int GXW = 2 * GT + 2;             // raw input columns per row (18)
-constexpr int GXP = 4 * GXW + 2;            // raw X pitch per channel (74: even, (c*74) mod 64 distinct evens)
-constexpr int GDP = 2 * 2 * GT + 2;         // raw dY pitch per channel (34)
-constexpr int GVS = 16 * GT * 32;           // one V plane slot / the dM buffer: [xi][tile][32] floats (4096)
-constexpr int kGLdsFloats = 3 * GVS + GVS + 32 * GXP + 32 * GDP;
+constexpr int GXP = 4 * GXW + 2;            // raw X pitch per channel (74: even -> 8-byte aligned patch rows)
+constexpr int GNB = 64;                     // rows (output channels) per workgroup
+constexpr int GVS = 16 * GT * 32;           // one V plane slot: [xi][tile][32 c] floats
+// dM buffer: [xi] pitch 545 : [k-step (tile pair)] pitch 136 : [row tile] 64 : [tile parity] 32 : [n & 31].
+// A fragment = 64 consecutive floats; the pitches spread the transform's writes (4 rows x 8 tiles x 2 dY rows per
+// wave instruction) over all 64 banks.
+constexpr int GMK = 136, GMX = 4 * GMK + 1, GMB = 16 * GMX;
+constexpr int GXB = 32 * GXP;               // one raw X buffer
+constexpr int kGLdsFloats = 4 * GVS + 2 * GMB + 2 * GXB;
 constexpr size_t kGLds = (size_t)kGLdsFloats * 4;
+static_assert(kGLds <= 160 * 1024, "LDS budget");
 
 typedef const __attribute__((address_space(1))) float* gfloat_p;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2* gfloat2_p;
 
 struct WinoWgradParams {
   ChanCat x;
@@ -39,209 +51,255 @@ struct WinoWgradParams {
   int Npad, Cpad;
 };
 
+__device__ __forceinline__ float dpp_xor8(float v) {   // value of lane ^ 8 (row_ror:8 inside a row of 16 lanes)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+}
+
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Vs = lds;                    // 3 slots [xi][tile][c]
-  float* Ms = lds + 3 * GVS;          // [xi][tile][n]
-  float* Xr = Ms + GVS;               // raw input rows of the new plane [c][4 rows][18]
-  float* Dr = Xr + 32 * GXP;          // raw dY rows [n][2 rows][16]
+  float* Vs = lds;                    // 4 slots [xi][tile][c]
+  float* Ms = lds + 4 * GVS;          // 2 buffers
+  float* Xr = Ms + 2 * GMB;           // 2 buffers of raw input rows [c][4 rows][18]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x, cb = blockIdx.y, nb = blockIdx.z;
+  // blocks of one split are neighbours in launch order: they walk the same columns at the same time, so the x rows
+  // (shared by all row blocks) and dY rows (shared by all channel blocks) are served by L2 / MALL
+  const int nblk_ = p.Npad / GNB, cblk_ = p.Cpad / 32;
+  const int split = blockIdx.x / (nblk_ * cblk_), q_ = blockIdx.x % (nblk_ * cblk_);
+  const int cb = q_ / nblk_, nb = q_ % nblk_;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
+  const int YX = p.Y * p.X;
 
-  f32x16 acc[6];   // [kz][xi - 2*wave]
+  f32x16 acc[12];   // [kz][xl][nt]
 #pragma unroll
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 12; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-  // ---- prefetch bookkeeping: this thread's raw elements (fixed positions inside a strip)
-  // X: 32 c x 4 rows x 18 cols = 2304 -> 5 per thread (the last partly);  dY: 32 n x 2 x 16 = 1024 -> 2 per thread
-  constexpr int NXE = (32 * 4 * GXW + 511) / 512;   // 5
-  int xe_c[NXE], xe_r[NXE], xe_x[NXE];
+  // ---- staging maps.
+  // X: wave w stages channels w, w+8, w+16, w+24 of the block; a channel's plane piece is 4 rows x 18 cols = 72
+  //    elements: lanes 0..63 take element `lane`, lanes 0..7 also element 64 + lane.
+  // dY: wave w feeds rows 8w .. 8w+7 as two groups of 4; lane = (row in group) * 16 + (dY row of the tile) * 8 + tile:
+  //    one float2 per lane and group, the other row of the 2x2 block comes from lane ^ 8.
+  const int xr0 = lane / GXW, xc0 = lane - xr0 * GXW;
+  const int xr1 = (64 + lane) / GXW, xc1 = (64 + lane) - xr1 * GXW;
+  const bool x1on = lane < 4 * GXW - 64;
+  const int dn4 = lane >> 4, dr = (lane >> 3) & 1, dtl = lane & 7;
+  // Base pointers of the current sample: wave-uniform (scalar registers), rebuilt when the batch index changes.
+  // The 4 dY rows of a group sit in the same slice (slice widths are multiples of 4: host dispatch), so row i is
+  // the group pointer + i * ZYX: one shared per-lane offset.
+  gfloat_p xcur[4], dcur[2];
+  auto set_batch = [&](const int b) {
 #pragma unroll
-  for (int i = 0; i < NXE; i++) {
-    const int e = tid + i * 512;
-    xe_c[i] = e / (4 * GXW);
-    const int r2 = e - xe_c[i] * (4 * GXW);
-    xe_r[i] = r2 / GXW, xe_x[i] = r2 - xe_r[i] * GXW;
-    if (e >= 32 * 4 * GXW) xe_c[i] = -1;
-  }
-  float px[NXE], pd[2];
+    for (int k = 0; k < 4; k++) {
+      const int gc = cb * 32 + wave + 8 * k;
+      xcur[k] = nullptr;
+      if (gc < p.Cin) {
+        const int si = cat_find(p.x, gc);
+        xcur[k] = (gfloat_p)cat_ptr(p.x, si) + (long long)(gc - cat_cbeg(p.x, si)) * ZYX + (long long)b * cat_bstride(p.x, si);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int gn = nb * GNB + wave * 8 + 4 * k;
+      dcur[k] = nullptr;
+      if (gn < p.N) {
+        const int si = cat_find(p.dy, gn);
+        dcur[k] = (gfloat_p)cat_ptr(p.dy, si) + (long long)(gn - cat_cbeg(p.dy, si)) * ZYX + (long long)b * cat_bstride(p.dy, si);
+      }
+    }
+  };
+  const long long dlane = (long long)dn4 * ZYX;
+  const gfloat_p dummy = (gfloat_p)p.x.ptr[0];
 
+  // ---- step generator (scalar state).  A segment = consecutive output planes oz_lo..oz_hi of one column; its
+  // steps bring planes oz_lo-1 .. oz_hi+1; the step of plane u completes output u-1 when u >= oz_lo+1.
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
   if (t_end > p.ntiles) t_end = p.ntiles;
-  int n_oz, n_tix, n_tiy, n_b;
+  long long t_next = t_begin;
+  int g_oz, g_tix, g_tiy, g_b;
   {
     long long r = t_begin;
-    n_oz = (int)(r % p.Z);
+    g_oz = (int)(r % p.Z);
     r /= p.Z;
-    n_tix = (int)(r % p.ntx);
+    g_tix = (int)(r % p.ntx);
     r /= p.ntx;
-    n_tiy = (int)(r % p.nty);
-    n_b = (int)(r / p.nty);
+    g_tiy = (int)(r % p.nty);
+    g_b = (int)(r / p.nty);
   }
-  int c_b = 0, c_oz = 0, c_y0 = 0, c_x0 = 0;
-  auto prep_next = [&]() {
-    c_oz = n_oz, c_b = n_b, c_y0 = n_tiy * 2, c_x0 = n_tix * (2 * GT);
-    if (++n_oz == p.Z) {
-      n_oz = 0;
-      if (++n_tix == p.ntx) {
-        n_tix = 0;
-        if (++n_tiy == p.nty) n_tiy = 0, ++n_b;
+  int s_u = 0, s_hi = -1, s_lo1 = 0, s_b = -1;
+  // per-lane values of the current column
+  int xoff0 = 0, xoff1 = 0, doffc = 0;
+  bool xok0 = false, xok1 = false, dok = false;
+  bool n_valid = false, n_out = false;   // descriptor of the step produced by next_step()
+  auto next_step = [&]() {
+    if (s_u < s_hi) {
+      s_u++;
+      n_valid = true;
+    } else if (t_next < t_end) {
+      const long long left = t_end - t_next;
+      const int len = (long long)(p.Z - g_oz) < left ? p.Z - g_oz : (int)left;
+      s_u = g_oz - 1, s_hi = g_oz + len, s_lo1 = g_oz + 1;
+      t_next += len;
+      if (g_b != s_b) set_batch(g_b), s_b = g_b;
+      const int y0 = g_tiy * 2, x0 = g_tix * (2 * GT);
+      g_oz = 0;
+      if (++g_tix == p.ntx) {
+        g_tix = 0;
+        if (++g_tiy == p.nty) g_tiy = 0, ++g_b;
       }
-    }
-  };
-  // raw rows of input plane gz of the strip (c_*) -> px
-  auto load_x = [&](const int gz) {
-#pragma unroll
-    for (int i = 0; i < NXE; i++) {
-      float v = 0.f;
-      const int gc = cb * 32 + xe_c[i];
-      const int gy = c_y0 - 1 + xe_r[i], gx = c_x0 - 1 + xe_x[i];
-      if (xe_c[i] >= 0 && gc < p.Cin && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y &&
-          (unsigned)gx < (unsigned)p.X) {
-        const int si = cat_find(p.x, gc);
-        v = ((gfloat_p)cat_ptr(p.x, si))[(long long)c_b * cat_bstride(p.x, si) + (long long)(gc - cat_cbeg(p.x, si)) * ZYX +
-                                          ((long long)gz * p.Y + gy) * p.X + gx];
-      }
-      px[i] = v;
-    }
-  };
-  auto store_x = [&]() {
-#pragma unroll
-    for (int i = 0; i < NXE; i++)
-      if (xe_c[i] >= 0) Xr[xe_c[i] * GXP + xe_r[i] * GXW + xe_x[i]] = px[i];
-  };
-  auto load_dy = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int e = tid + i * 512;            // 32 n x 32 voxels
-      const int n = e >> 5, r = (e >> 4) & 1, xx = e & 15;
-      const int gn = nb * 32 + n, gy = c_y0 + r, gx = c_x0 + xx;
-      float v = 0.f;
-      if (gn < p.N && gy < p.Y && gx < p.X) {
-        const int si = cat_find(p.dy, gn);
-        v = ((gfloat_p)cat_ptr(p.dy, si))[(long long)c_b * cat_bstride(p.dy, si) + (long long)(gn - cat_cbeg(p.dy, si)) * ZYX +
-                                           ((long long)c_oz * p.Y + gy) * p.X + gx];
-      }
-      pd[i] = v;
-    }
-  };
-  auto store_dy = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int e = tid + i * 512;
-      Dr[(e >> 5) * GDP + ((e >> 4) & 1) * (2 * GT) + (e & 15)] = pd[i];
-    }
-  };
-  // threads 0..255: (c, tile) patch of the raw plane -> V slot;   [xi][tile][c]
-  auto transform_v = [&](float* V) {
-    const int c = tid & 31, tl = (tid >> 5) & 7;
-    const float* rp = Xr + c * GXP + 2 * tl;
-    float d[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const f32x2 a = *reinterpret_cast<const f32x2*>(rp + i * GXW);
-      const f32x2 b2 = *reinterpret_cast<const f32x2*>(rp + i * GXW + 2);
-      d[i][0] = a.x, d[i][1] = a.y, d[i][2] = b2.x, d[i][3] = b2.y;
-    }
-    float tt[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      tt[i][0] = d[i][0] - d[i][2];
-      tt[i][1] = d[i][1] + d[i][2];
-      tt[i][2] = d[i][2] - d[i][1];
-      tt[i][3] = d[i][1] - d[i][3];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      V[((0 * 4 + j) * GT + tl) * 32 + c] = tt[0][j] - tt[2][j];
-      V[((1 * 4 + j) * GT + tl) * 32 + c] = tt[1][j] + tt[2][j];
-      V[((2 * 4 + j) * GT + tl) * 32 + c] = tt[2][j] - tt[1][j];
-      V[((3 * 4 + j) * GT + tl) * 32 + c] = tt[1][j] - tt[3][j];
-    }
-  };
-  // threads 256..511: (n, tile) 2x2 block of dY -> dM = A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]
-  auto transform_m = [&]() {
-    const int n = tid & 31, tl = (tid >> 5) & 7;
-    const float* rp = Dr + n * GDP + 2 * tl;
-    const f32x2 r0 = *reinterpret_cast<const f32x2*>(rp);
-    const f32x2 r1 = *reinterpret_cast<const f32x2*>(rp + 2 * GT);
-    float t0[4] = {r0.x, r0.x + r0.y, r0.x - r0.y, -r0.y};
-    float t1[4] = {r1.x, r1.x + r1.y, r1.x - r1.y, -r1.y};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      Ms[((0 * 4 + j) * GT + tl) * 32 + n] = t0[j];
-      Ms[((1 * 4 + j) * GT + tl) * 32 + n] = t0[j] + t1[j];
-      Ms[((2 * 4 + j) * GT + tl) * 32 + n] = t0[j] - t1[j];
-      Ms[((3 * 4 + j) * GT + tl) * 32 + n] = -t1[j];
-    }
-  };
-
-  bool fresh = true;
-  int s0 = 0;   // slot of the plane kz = 0 of the current strip
-  if (t_begin < t_end) {
-    prep_next();
-    load_dy();
-  }
-  const int fb = (lane >> 5) * 32 + (lane & 31);   // fragment offset inside [tile pair][32]
-
-  for (long long tile = t_begin; tile < t_end; tile++) {
-    __syncthreads();   // previous strip's MFMAs are done: raw buffers, dM and the oldest V slot are free
-    if (fresh) {
-      // start of a z column: planes oz-1 and oz are transformed here, oz+1 joins the normal path below
-      s0 = 0;
-      for (int k = 0; k < 2; k++) {
-        load_x(c_oz - 1 + k);
-        store_x();
-        __syncthreads();
-        if (tid < 256) transform_v(Vs + k * GVS);
-        __syncthreads();
-      }
-      load_x(c_oz + 1);
+      const int gy0 = y0 - 1 + xr0, gx0 = x0 - 1 + xc0, gy1 = y0 - 1 + xr1, gx1 = x0 - 1 + xc1;
+      xok0 = (unsigned)gy0 < (unsigned)p.Y && (unsigned)gx0 < (unsigned)p.X;
+      xok1 = x1on && (unsigned)gy1 < (unsigned)p.Y && (unsigned)gx1 < (unsigned)p.X;
+      xoff0 = xok0 ? gy0 * p.X + gx0 : 0;
+      xoff1 = xok1 ? gy1 * p.X + gx1 : 0;
+      const int gy = y0 + dr, gx = x0 + 2 * dtl;
+      dok = gy < p.Y && gx < p.X;   // X is even (host dispatch): gx + 1 is valid with gx
+      doffc = dok ? gy * p.X + gx : 0;
+      n_valid = true;
     } else {
-      s0 = (s0 + 1) % 3;
+      n_valid = false;
     }
-    store_x();    // plane oz+1 (prefetched during the previous strip, or just loaded)
-    store_dy();
-    __syncthreads();
-    if (tid < 256)
-      transform_v(Vs + ((s0 + 2) % 3) * GVS);
-    else
-      transform_m();
-    __syncthreads();
+    n_out = n_valid && s_u >= s_lo1;
+  };
 
-    const bool more = tile + 1 < t_end;
-    const int cur_oz = c_oz;
-    if (more) {
-      prep_next();
-      fresh = c_oz == 0;
-      if (!fresh) load_x(c_oz + 1);   // in flight during the MFMA phase
-      load_dy();
+  float px[4][2];
+  f32x2 pd[2];
+  bool pzok = false;
+  // raw rows of input plane s_u of the current column -> px (branch-free: invalid elements read a dummy address)
+  auto load_x = [&]() {
+    pzok = (unsigned)s_u < (unsigned)p.Z;
+    const int zo = pzok ? s_u * YX : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const gfloat_p base = xcur[k] != nullptr ? xcur[k] + zo : dummy;
+      px[k][0] = base[xoff0];
+      px[k][1] = base[xoff1];
     }
-    (void)cur_oz;
-
-    const float* v0p = Vs + s0 * GVS + fb;
-    const float* v1p = Vs + ((s0 + 1) % 3) * GVS + fb;
-    const float* v2p = Vs + ((s0 + 2) % 3) * GVS + fb;
-    const float* mp = Ms + fb;
+  };
+  auto store_x = [&](float* buf) {
 #pragma unroll
-    for (int ks = 0; ks < GT / 2; ks++) {
+    for (int k = 0; k < 4; k++) {
+      const bool cok = xcur[k] != nullptr && pzok;
+      float* row = buf + (wave + 8 * k) * GXP;
+      row[lane] = (cok && xok0) ? px[k][0] : 0.f;
+      if (x1on) row[64 + lane] = (cok && xok1) ? px[k][1] : 0.f;
+    }
+  };
+  // dY rows of output plane s_u - 1 -> pd
+  auto load_dy = [&]() {
+    const int zo = (s_u - 1) * YX;
 #pragma unroll
-      for (int xl = 0; xl < 2; xl++) {
-        const int xi = 2 * wave + xl;
-        const int o = (xi * GT + 2 * ks) * 32;
-        const float a = mp[o];
-        const float b0 = v0p[o], b1 = v1p[o], b2 = v2p[o];
-        acc[0 * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0 * 2 + xl], 0, 0, 0);
-        acc[1 * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1 * 2 + xl], 0, 0, 0);
-        acc[2 * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2 * 2 + xl], 0, 0, 0);
+    for (int k = 0; k < 2; k++) {
+      const gfloat_p base = dcur[k] != nullptr ? dcur[k] + dlane + zo : dummy;
+      pd[k] = *(gfloat2_p)(base + doffc);
+    }
+  };
+  // dM = A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1].  With a = T(own row), b = T(other row), T(v) = (x, x+y, x-y, -y):
+  //   dY row 0 lanes write xi_y = 0: a,   xi_y = 1: a + b;     dY row 1 lanes write xi_y = 3: -a,   xi_y = 2: b - a.
+  const float msign = dr ? -1.f : 1.f;
+  const int m_p = (dr ? 12 : 0) * GMX + (dtl >> 1) * GMK + (wave >> 2) * 64 + (dtl & 1) * 32 + ((wave * 8 + dn4) & 31);
+  const int m_q = (dr ? 8 : 4) * GMX + (dtl >> 1) * GMK + (wave >> 2) * 64 + (dtl & 1) * 32 + ((wave * 8 + dn4) & 31);
+  auto transform_m = [&](float* M, const bool ok) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const bool v = ok && dcur[k] != nullptr;
+      const float rx = v ? pd[k].x : 0.f, ry = v ? pd[k].y : 0.f;
+      const float tx = dpp_xor8(rx), ty = dpp_xor8(ry);   // the other dY row of the 2x2 block
+      const float ox = rx * msign, oy = ry * msign;       // sigma * own row
+      const float a[4] = {ox, ox + oy, ox - oy, -oy};
+      const float b[4] = {tx, tx + ty, tx - ty, -ty};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        M[m_p + 4 * k + j * GMX] = a[j];
+        M[m_q + 4 * k + j * GMX] = b[j] + a[j];
       }
     }
+  };
+  // V = B^T d B of the (c, tile) patch, half of the columns per thread: waves 0-3 produce xi_x = 0, 1 (from patch
+  // columns 0, 1, 2), waves 4-7 xi_x = 2, 3 (from columns 2, 3 and 1); same code, different offsets and one sign.
+  const int vh = wave >> 2;
+  const int tc = tid & 31, ttl = (tid >> 5) & 7;
+  const int v_rd2 = tc * GXP + 2 * ttl + (vh ? 2 : 0), v_rd1 = tc * GXP + 2 * ttl + (vh ? 1 : 2);
+  const int v_wr = (2 * vh) * (GT * 32) + ttl * 32 + tc;
+  const float vsign = vh ? -1.f : 1.f;
+  float vt[4][2];
+  auto tv_read = [&](const float* raw) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const f32x2 pq = *reinterpret_cast<const f32x2*>(raw + v_rd2 + i * GXW);
+      const float r = raw[v_rd1 + i * GXW];
+      vt[i][0] = pq.x - r;
+      vt[i][1] = fmaf(pq.y, vsign, r);
+    }
+  };
+  auto tv_write = [&](float* V) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+      V[v_wr + (0 * 4 + jj) * (GT * 32)] = vt[0][jj] - vt[2][jj];
+      V[v_wr + (1 * 4 + jj) * (GT * 32)] = vt[1][jj] + vt[2][jj];
+      V[v_wr + (2 * 4 + jj) * (GT * 32)] = vt[2][jj] - vt[1][jj];
+      V[v_wr + (3 * 4 + jj) * (GT * 32)] = vt[1][jj] - vt[3][jj];
+    }
+  };
+
+  // ---- prologue: raw rows of step 0
+  next_step();
+  bool cur_valid = n_valid, cur_out = n_out, cur_dok = false, prev_out = false;
+  if (cur_valid) {
+    load_x();
+    store_x(Xr);
+  }
+  __syncthreads();
+
+  const int fl = lane;   // fragments are 64 consecutive floats
+  for (int s = 0; cur_valid || prev_out; s++) {
+    if (cur_out) transform_m(Ms + (s & 1) * GMB, cur_dok);
+    next_step();
+    const bool nxt_valid = n_valid, nxt_out = n_out;
+    if (nxt_valid) {
+      load_x();
+      if (nxt_out) load_dy();
+    }
+    const float* raw = Xr + (s & 1) * GXB;
+    float* vnew = Vs + (s & 3) * GVS;
+    if (prev_out) {
+      const float* v0p = Vs + ((s + 1) & 3) * GVS + fl;
+      const float* v1p = Vs + ((s + 2) & 3) * GVS + fl;
+      const float* v2p = Vs + ((s + 3) & 3) * GVS + fl;
+      const float* mp = Ms + ((s + 1) & 1) * GMB + fl;
+      tv_read(raw);
+#pragma unroll
+      for (int ks = 0; ks < GT / 2; ks++) {
+        float a[2][2], bq[2][3];
+#pragma unroll
+        for (int xl = 0; xl < 2; xl++) {
+          const int xi = 2 * wave + xl;
+          a[xl][0] = mp[xi * GMX + ks * GMK];
+          a[xl][1] = mp[xi * GMX + ks * GMK + 64];
+          const int o = (xi * GT + 2 * ks) * 32;
+          bq[xl][0] = v0p[o], bq[xl][1] = v1p[o], bq[xl][2] = v2p[o];
+        }
+        if (ks == 1) tv_write(vnew);
+#pragma unroll
+        for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+          for (int xl = 0; xl < 2; xl++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+              acc[(kz * 2 + xl) * 2 + nt] =
+                  __builtin_amdgcn_mfma_f32_32x32x2f32(a[xl][nt], bq[xl][kz], acc[(kz * 2 + xl) * 2 + nt], 0, 0, 0);
+      }
+    } else {
+      tv_read(raw);
+      tv_write(vnew);
+    }
+    if (nxt_valid) store_x(Xr + ((s + 1) & 1) * GXB);
+    __syncthreads();
+    prev_out = cur_out;
+    cur_valid = nxt_valid, cur_out = nxt_out, cur_dok = dok;
   }
 
   // ---- partial dU block -> slab[split][kz*16 + xi][n][c]
@@ -249,15 +307,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
 #pragma unroll
   for (int kz = 0; kz < 3; kz++)
 #pragma unroll
-    for (int xl = 0; xl < 2; xl++) {
-      const int q = kz * 16 + 2 * wave + xl;
-      float* dst = p.slab + (((long long)split * 48 + q) * p.Npad + nb * 32) * p.Cpad + c;
+    for (int xl = 0; xl < 2; xl++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        dst[(long long)n * p.Cpad] = acc[kz * 2 + xl][r];
+      for (int nt = 0; nt < 2; nt++) {
+        const int q = kz * 16 + 2 * wave + xl;
+        float* dst = p.slab + (((long long)split * 48 + q) * p.Npad + nb * GNB + nt * 32) * p.Cpad + c;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          dst[(long long)n * p.Cpad] = acc[(kz * 2 + xl) * 2 + nt][r];
+        }
       }
-    }
 }
 
 // dW[n][c][kz][ky][kx] = sum_{xi} G[xi_y][ky] G[xi_x][kx] * (sum_s slab[s][kz*16 + xi][n][c])
@@ -302,8 +362,8 @@ struct GPlan {
 
 GPlan gplan(const sr3d_conv_desc_t* d, int n_total) {
   GPlan g;
-  g.nblk = ceil_div(n_total, 32), g.cblk = ceil_div(d->Cin, 32);
-  g.Npad = g.nblk * 32, g.Cpad = g.cblk * 32;
+  g.nblk = ceil_div(n_total, GNB), g.cblk = ceil_div(d->Cin, 32);
+  g.Npad = g.nblk * GNB, g.Cpad = g.cblk * 32;
   g.nty = ceil_div(d->Y, 2), g.ntx = ceil_div(d->X, 2 * GT);
   g.ntiles = (long long)d->B * g.nty * g.ntx * d->Z;
   long long want = ceil_div(1280, g.nblk * g.cblk);
@@ -341,7 +401,7 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   void* tok = nullptr;
   if (sr3d_prof_active())
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st, &tok);
-  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(g.S, g.cblk, g.nblk), dim3(512), kGLds, st, p);
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(g.S * g.cblk * g.nblk), dim3(512), kGLds, st, p);
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
   const long long total = (long long)n_total * d->Cin * 3;
