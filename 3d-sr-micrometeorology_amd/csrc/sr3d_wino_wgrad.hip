@@ -18,6 +18,7 @@
 //                   raw x rows of step s+1 -> LDS  |  ONE barrier
 // All LDS layouts are bank-conflict-free by construction (see the pitch constants), the global base pointers are
 // wave-uniform, everything depending only on the lane is computed once per column.
+#include <algorithm>
 #include "sr3d_common.h"
 
 namespace {
@@ -32,7 +33,7 @@ constexpr int GVS = 16 * GT * 32;           // one V plane slot: [xi][tile][32 c
 // wave instruction) over all 64 banks.
 constexpr int GMK = 136, GMX = 4 * GMK + 1, GMB = 16 * GMX;
 constexpr int GXB = 32 * GXP;               // one raw X buffer
-constexpr int kGLdsFloats = 4 * GVS + 2 * GMB + 2 * GXB;
+constexpr int kGLdsFloats = 4 * GVS + 2 * GMB + 3 * GXB;
 constexpr size_t kGLds = (size_t)kGLdsFloats * 4;
 static_assert(kGLds <= 160 * 1024, "LDS budget");
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Vs = lds;                    // 4 slots [xi][tile][c]
   float* Ms = lds + 4 * GVS;          // 2 buffers
-  float* Xr = Ms + 2 * GMB;           // 2 buffers of raw input rows [c][4 rows][18]
+  float* Xr = Ms + 2 * GMB;           // 3 buffers of raw input rows [c][4 rows][18]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,13 +83,16 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   //    elements: lanes 0..63 take element `lane`, lanes 0..7 also element 64 + lane.
   // dY: wave w feeds rows 8w .. 8w+7 as two groups of 4; lane = (row in group) * 16 + (dY row of the tile) * 8 + tile:
   //    one float2 per lane and group, the other row of the 2x2 block comes from lane ^ 8.
+  // All global reads are raw BUFFER loads: the descriptor (scalar registers) covers exactly one channel plane
+  // (x) / the group's rows of the sample (dY), so padding, ragged tiles, planes -1 and Z and channels beyond
+  // Cin / N need no masks at all: their byte offset is out of range and the hardware returns 0.
   const int xr0 = lane / GXW, xc0 = lane - xr0 * GXW;
   const int xr1 = (64 + lane) / GXW, xc1 = (64 + lane) - xr1 * GXW;
   const bool x1on = lane < 4 * GXW - 64;
   const int dn4 = lane >> 4, dr = (lane >> 3) & 1, dtl = lane & 7;
   // Base pointers of the current sample: wave-uniform (scalar registers), rebuilt when the batch index changes.
   // The 4 dY rows of a group sit in the same slice (slice widths are multiples of 4: host dispatch), so row i is
-  // the group pointer + i * ZYX: one shared per-lane offset.
+  // the group pointer + i * ZYX: part of the per-lane byte offset.
   gfloat_p xcur[4], dcur[2];
   auto set_batch = [&](const int b) {
 #pragma unroll
@@ -110,8 +114,9 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
       }
     }
   };
-  const long long dlane = (long long)dn4 * ZYX;
-  const gfloat_p dummy = (gfloat_p)p.x.ptr[0];
+  const unsigned kOob = 0xffffffffu;
+  const int plane_bytes = YX * 4;
+  const int dy_bytes = (int)(ZYX * 16);   // 4 rows of the sample (host dispatch guarantees ZYX * 16 < 2^31)
 
   // ---- step generator (scalar state).  A segment = consecutive output planes oz_lo..oz_hi of one column; its
   // steps bring planes oz_lo-1 .. oz_hi+1; the step of plane u completes output u-1 when u >= oz_lo+1.
@@ -130,10 +135,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     g_b = (int)(r / p.nty);
   }
   int s_u = 0, s_hi = -1, s_lo1 = 0, s_b = -1;
-  // per-lane values of the current column
-  int xoff0 = 0, xoff1 = 0, doffc = 0;
-  bool xok0 = false, xok1 = false, dok = false;
-  bool n_valid = false, n_out = false;   // descriptor of the step produced by next_step()
+  unsigned xoff0 = kOob, xoff1 = kOob, doffc = kOob;   // per-lane byte offsets inside the plane / the dY rows
+  bool n_valid = false, n_out = false;                 // descriptor of the step produced by next_step()
   auto next_step = [&]() {
     if (s_u < s_hi) {
       s_u++;
@@ -151,13 +154,13 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
         if (++g_tiy == p.nty) g_tiy = 0, ++g_b;
       }
       const int gy0 = y0 - 1 + xr0, gx0 = x0 - 1 + xc0, gy1 = y0 - 1 + xr1, gx1 = x0 - 1 + xc1;
-      xok0 = (unsigned)gy0 < (unsigned)p.Y && (unsigned)gx0 < (unsigned)p.X;
-      xok1 = x1on && (unsigned)gy1 < (unsigned)p.Y && (unsigned)gx1 < (unsigned)p.X;
-      xoff0 = xok0 ? gy0 * p.X + gx0 : 0;
-      xoff1 = xok1 ? gy1 * p.X + gx1 : 0;
+      const bool ok0 = (unsigned)gy0 < (unsigned)p.Y && (unsigned)gx0 < (unsigned)p.X;
+      const bool ok1 = x1on && (unsigned)gy1 < (unsigned)p.Y && (unsigned)gx1 < (unsigned)p.X;
+      xoff0 = ok0 ? (unsigned)(gy0 * p.X + gx0) * 4u : kOob;
+      xoff1 = ok1 ? (unsigned)(gy1 * p.X + gx1) * 4u : kOob;
       const int gy = y0 + dr, gx = x0 + 2 * dtl;
-      dok = gy < p.Y && gx < p.X;   // X is even (host dispatch): gx + 1 is valid with gx
-      doffc = dok ? gy * p.X + gx : 0;
+      const bool dok = gy < p.Y && gx < p.X;   // X is even (host dispatch): gx + 1 is valid with gx
+      doffc = dok ? (unsigned)(dn4 * (int)ZYX + gy * p.X + gx) * 4u : kOob;
       n_valid = true;
     } else {
       n_valid = false;
@@ -165,36 +168,36 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     n_out = n_valid && s_u >= s_lo1;
   };
 
-  float px[4][2];
   f32x2 pd[2];
-  bool pzok = false;
-  // raw rows of input plane s_u of the current column -> px (branch-free: invalid elements read a dummy address)
-  auto load_x = [&]() {
-    pzok = (unsigned)s_u < (unsigned)p.Z;
-    const int zo = pzok ? s_u * YX : 0;
+  typedef __attribute__((address_space(3))) void* lds_p;
+  // raw rows of input plane s_u of the current column -> LDS buffer `buf`, straight from the buffer load (no
+  // registers, no ds_write): lane i of the wave instruction lands at row + 4 i bytes, which is the row layout.
+  auto load_x = [&](float* buf) {
+    const bool zok = n_valid && (unsigned)s_u < (unsigned)p.Z;
+    const long long zo = (long long)s_u * YX;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const gfloat_p base = xcur[k] != nullptr ? xcur[k] + zo : dummy;
-      px[k][0] = base[xoff0];
-      px[k][1] = base[xoff1];
-    }
-  };
-  auto store_x = [&](float* buf) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool cok = xcur[k] != nullptr && pzok;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(xcur[k] + zo), 0, (zok && xcur[k] != nullptr) ? plane_bytes : 0, 0x00020000);
       float* row = buf + (wave + 8 * k) * GXP;
-      row[lane] = (cok && xok0) ? px[k][0] : 0.f;
-      if (x1on) row[64 + lane] = (cok && xok1) ? px[k][1] : 0.f;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)row, 4, xoff0, 0, 0, 0);
+      if (x1on) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)(row + 64), 4, xoff1, 0, 0, 0);
     }
   };
-  // dY rows of output plane s_u - 1 -> pd
+  // dY rows of the output completed by the step BEFORE the generator's current one (the generator runs two steps
+  // ahead for x, dY is fetched one step ahead): lagged copy of its state
+  int lag_u = 0;
+  bool lag_out = false;
+  unsigned lag_doffc = kOob;
+  gfloat_p lag_d[2] = {nullptr, nullptr};
+  auto lag_state = [&]() { lag_u = s_u, lag_out = n_out, lag_doffc = doffc, lag_d[0] = dcur[0], lag_d[1] = dcur[1]; };
   auto load_dy = [&]() {
-    const int zo = (s_u - 1) * YX;
+    const long long zo = (long long)(lag_u - 1) * YX;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const gfloat_p base = dcur[k] != nullptr ? dcur[k] + dlane + zo : dummy;
-      pd[k] = *(gfloat2_p)(base + doffc);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(lag_d[k] + zo), 0, (lag_out && lag_d[k] != nullptr) ? dy_bytes : 0, 0x00020000);
+      pd[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, lag_doffc, 0, 0));
     }
   };
   // dM = A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1].  With a = T(own row), b = T(other row), T(v) = (x, x+y, x-y, -y):
@@ -202,11 +205,10 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   const float msign = dr ? -1.f : 1.f;
   const int m_p = (dr ? 12 : 0) * GMX + (dtl >> 1) * GMK + (wave >> 2) * 64 + (dtl & 1) * 32 + ((wave * 8 + dn4) & 31);
   const int m_q = (dr ? 8 : 4) * GMX + (dtl >> 1) * GMK + (wave >> 2) * 64 + (dtl & 1) * 32 + ((wave * 8 + dn4) & 31);
-  auto transform_m = [&](float* M, const bool ok) {
+  auto transform_m = [&](float* M) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const bool v = ok && dcur[k] != nullptr;
-      const float rx = v ? pd[k].x : 0.f, ry = v ? pd[k].y : 0.f;
+      const float rx = pd[k].x, ry = pd[k].y;
       const float tx = dpp_xor8(rx), ty = dpp_xor8(ry);   // the other dY row of the 2x2 block
       const float ox = rx * msign, oy = ry * msign;       // sigma * own row
       const float a[4] = {ox, ox + oy, ox - oy, -oy};
@@ -245,61 +247,81 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     }
   };
 
-  // ---- prologue: raw rows of step 0
+  // ---- prologue: LDS starts finite (the first MFMAs of a segment multiply stale V planes by a zero dM), raw rows
+  // of step 0
+  for (int i = tid; i < 4 * GVS + 2 * GMB; i += 512) lds[i] = 0.f;
   next_step();
-  bool cur_valid = n_valid, cur_out = n_out, cur_dok = false, prev_out = false;
-  if (cur_valid) {
-    load_x();
-    store_x(Xr);
-  }
+  bool cur_valid = n_valid, prev_out = false, cur_out = n_out;
+  load_x(Xr);                      // step 0
+  next_step();
+  bool nx_valid = n_valid, nx_out = n_out;
+  load_x(Xr + GXB);                // step 1
+  pd[0] = pd[1] = f32x2{0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // ---- main loop: ONE straight-line block per plane step.  Every stage always runs; a stage without work sees
+  // zeros (empty buffer descriptors) instead of being branched around, so that the dM transform, the descriptor
+  // arithmetic, the global loads and the V transform sit in the shadow of the MFMAs.  Fragments are double-
+  // buffered in registers: a wave that is alone on its SIMD still issues MFMAs back to back.
+  // Global loads run two steps ahead for x (three raw LDS buffers) and one full step ahead for dY.
   const int fl = lane;   // fragments are 64 consecutive floats
+  int rb = 0;            // raw buffer of step s
   for (int s = 0; cur_valid || prev_out; s++) {
-    if (cur_out) transform_m(Ms + (s & 1) * GMB, cur_dok);
-    next_step();
-    const bool nxt_valid = n_valid, nxt_out = n_out;
-    if (nxt_valid) {
-      load_x();
-      if (nxt_out) load_dy();
-    }
-    const float* raw = Xr + (s & 1) * GXB;
-    float* vnew = Vs + (s & 3) * GVS;
-    if (prev_out) {
-      const float* v0p = Vs + ((s + 1) & 3) * GVS + fl;
-      const float* v1p = Vs + ((s + 2) & 3) * GVS + fl;
-      const float* v2p = Vs + ((s + 3) & 3) * GVS + fl;
-      const float* mp = Ms + ((s + 1) & 1) * GMB + fl;
-      tv_read(raw);
+    const int rb2 = rb >= 1 ? rb - 1 : 2;   // (rb + 2) % 3
+    lag_state();                  // step s+1
+    next_step();                  // -> step s+2 (scalar; per-lane offsets only when a new column starts)
+    load_x(Xr + rb2 * GXB);       // its rows: global -> LDS, two steps of latency budget
+    const float* v0p = Vs + ((s + 1) & 3) * GVS + fl;
+    const float* v1p = Vs + ((s + 2) & 3) * GVS + fl;
+    const float* v2p = Vs + ((s + 3) & 3) * GVS + fl;
+    const float* mp = Ms + ((s + 1) & 1) * GMB + fl;
+    float a[2][2][2], bq[2][2][3];
+    auto frags = [&](const int ks, const int set) {
 #pragma unroll
-      for (int ks = 0; ks < GT / 2; ks++) {
-        float a[2][2], bq[2][3];
-#pragma unroll
-        for (int xl = 0; xl < 2; xl++) {
-          const int xi = 2 * wave + xl;
-          a[xl][0] = mp[xi * GMX + ks * GMK];
-          a[xl][1] = mp[xi * GMX + ks * GMK + 64];
-          const int o = (xi * GT + 2 * ks) * 32;
-          bq[xl][0] = v0p[o], bq[xl][1] = v1p[o], bq[xl][2] = v2p[o];
-        }
-        if (ks == 1) tv_write(vnew);
-#pragma unroll
-        for (int kz = 0; kz < 3; kz++)
-#pragma unroll
-          for (int xl = 0; xl < 2; xl++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-              acc[(kz * 2 + xl) * 2 + nt] =
-                  __builtin_amdgcn_mfma_f32_32x32x2f32(a[xl][nt], bq[xl][kz], acc[(kz * 2 + xl) * 2 + nt], 0, 0, 0);
+      for (int xl = 0; xl < 2; xl++) {
+        const int xi = 2 * wave + xl;
+        a[set][xl][0] = mp[xi * GMX + ks * GMK];
+        a[set][xl][1] = mp[xi * GMX + ks * GMK + 64];
+        const int o = (xi * GT + 2 * ks) * 32;
+        bq[set][xl][0] = v0p[o], bq[set][xl][1] = v1p[o], bq[set][xl][2] = v2p[o];
       }
-    } else {
-      tv_read(raw);
-      tv_write(vnew);
-    }
-    if (nxt_valid) store_x(Xr + ((s + 1) & 1) * GXB);
-    __syncthreads();
+    };
+    auto mfmas = [&](const int set) {
+#pragma unroll
+      for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+        for (int xl = 0; xl < 2; xl++)
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++)
+            acc[(kz * 2 + xl) * 2 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                a[set][xl][nt], bq[set][xl][kz], acc[(kz * 2 + xl) * 2 + nt], 0, 0, 0);
+    };
+    frags(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(1, 1);
+    tv_read(Xr + rb * GXB);
+    mfmas(0);                             // output completed by step s-1 (zero dM if there is none)
+    tv_write(Vs + (s & 3) * GVS);         // V of step s's plane
+    __builtin_amdgcn_sched_barrier(0);
+    frags(2, 0);
+    mfmas(1);
+    transform_m(Ms + (s & 1) * GMB);      // dM of step s's output (dY rows loaded during step s-1)
+    __builtin_amdgcn_sched_barrier(0);
+    load_dy();                            // dY rows of step s+1's output: a full step of latency budget
+    frags(3, 1);
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // the rows of step s+1 (issued one step ago) have landed; younger loads (12 per wave) may stay in flight
+    // (a bare s_barrier: __syncthreads() carries a release fence that would drain the younger LDS-DMA loads too)
+    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     prev_out = cur_out;
-    cur_valid = nxt_valid, cur_out = nxt_out, cur_dok = dok;
+    cur_valid = nx_valid, cur_out = nx_out;
+    nx_valid = n_valid, nx_out = n_out;
+    rb = rb == 2 ? 0 : rb + 1;
   }
 
   // ---- partial dU block -> slab[split][kz*16 + xi][n][c]
@@ -318,6 +340,23 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
           dst[(long long)n * p.Cpad] = acc[(kz * 2 + xl) * 2 + nt][r];
         }
       }
+}
+
+// slab[0][e] = sum_s slab[s][e]  (fixed order: deterministic; in place: a thread only touches its own elements)
+__global__ __launch_bounds__(256) void wino_wgrad_sum_kernel(float* __restrict__ slab, int S, long long count) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+       e += (long long)gridDim.x * blockDim.x) {
+    const float* src = slab + e;
+    float s = src[0];
+    int k = 1;
+    for (; k + 4 <= S; k += 4) {
+      const float v0 = src[(long long)k * count], v1 = src[(long long)(k + 1) * count];
+      const float v2 = src[(long long)(k + 2) * count], v3 = src[(long long)(k + 3) * count];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < S; k++) s += src[(long long)k * count];
+    slab[e] = s;
+  }
 }
 
 // dW[n][c][kz][ky][kx] = sum_{xi} G[xi_y][ky] G[xi_x][kx] * (sum_s slab[s][kz*16 + xi][n][c])
@@ -366,11 +405,17 @@ GPlan gplan(const sr3d_conv_desc_t* d, int n_total) {
   g.Npad = g.nblk * GNB, g.Cpad = g.cblk * 32;
   g.nty = ceil_div(d->Y, 2), g.ntx = ceil_div(d->X, 2 * GT);
   g.ntiles = (long long)d->B * g.nty * g.ntx * d->Z;
-  long long want = ceil_div(1280, g.nblk * g.cblk);
+  // One workgroup per CU and every workgroup does the same amount of work: make the grid a whole number of rounds
+  // over the 256 CUs (5 rounds if the slab cap allows it), otherwise as many splits as the cap allows.
+  const int R = g.nblk * g.cblk;
   const long long slab_one = (long long)48 * g.Npad * g.Cpad * 4;
-  const long long cap = (256ll << 20) / slab_one;
+  const long long cap = std::max(1ll, (384ll << 20) / slab_one);
+  long long want = 1;
+  for (int rounds = 5; rounds >= 1; rounds--) {
+    want = std::max(1ll, (256ll * rounds) / R);
+    if (want <= cap) break;
+  }
   if (want > cap) want = cap;
-  if (want < 1) want = 1;
   if (want > g.ntiles) want = g.ntiles;
   g.per_split = (g.ntiles + want - 1) / want;
   g.S = (int)((g.ntiles + g.per_split - 1) / g.per_split);
@@ -406,7 +451,13 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   SR3D_HIP(hipGetLastError());
   const long long total = (long long)n_total * d->Cin * 3;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, g.S, n_total,
+  if (g.S > 1) {
+    const long long count = (long long)48 * g.Npad * g.Cpad;
+    const int sblocks = (int)std::min<long long>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(sblocks), dim3(256), 0, st, ws, g.S, count);
+    SR3D_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, 1, n_total,
                      d->Cin, g.Npad, g.Cpad);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
