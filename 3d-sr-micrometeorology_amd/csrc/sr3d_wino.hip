@@ -7,19 +7,24 @@
 // (measured normwise error vs fp64 3e-7, the same as the direct fp32 kernel; all arithmetic is still fp32).
 //
 //   U[kz][xi][c][n] = (G w[n][c][kz] G^T)[xi]              weights, transformed once per call (wino_pack_kernel)
-//   V[xi][c][tile]  = (B^T d B)[xi]                         4x4 input patch of a 2x2 output tile, on the fly
-//   M[xi][n][tile] += sum_c U[kz][xi][c][n] * V[xi][c][tile]     <- 16 independent GEMMs = the MFMA work
-//   Y[n][tile 2x2]  = A^T M A                               epilogue
+//   V[z][xi][c][tile] = (B^T d B)[xi]                       4x4 input patch of a 2x2 output tile
+//   M[xi][n][z][tile] += sum_{c,kz} U[kz][xi][c][n] * V[z+kz][xi][c][tile]    <- 16 independent GEMMs = MFMA work
+//   Y[n][z][tile 2x2]  = A^T M A                            epilogue
 //
-// Mapping: MFMA rows = 32 output channels (A operand = U, read from LDS), MFMA columns = 32 tiles (2 tile
-// rows x 16 tile columns = 4 x 32 voxels of one z plane).  The lane that owns column `tile` and k-slot
-// `lane>>5` transforms exactly that (tile, channel) patch, so the 16 transformed values ARE its B operands
-// for the MFMAs of the k-step -- V never goes through LDS.  A 512-thread workgroup covers a 4x4x32-voxel
-// block: wave w works on z plane w&3 and on the xi rows 2*(w>>2), 2*(w>>2)+1 (8 accumulators = 128 VGPRs),
-// so the two waves that share a SIMD (w, w+4) split the 16 transform points of the same tiles and their
-// partial output transforms are added through LDS in the epilogue.  One workgroup per CU, two waves per SIMD.
-// Staging is double buffered: raw input halo through registers (issued before, written after the MFMA
-// phase of the previous chunk), transformed weights by LDS-DMA.
+// One 512-thread workgroup (alone on its CU) owns 64 output rows x 3 z planes x (4 x 32 voxels = 32 tiles).
+// Wave w keeps the transform points xi = 2w, 2w+1 for both 32-row tiles and the 3 planes: 12 accumulators.  Both
+// operands come from LDS as plain 64-float fragments: U by LDS-DMA from the packed image, V written ONCE per
+// workgroup and chunk by a cooperative transform (5 input planes x 2 channels x 32 tiles, half a patch per
+// thread) and then shared by the 64 rows and the 3 kz taps.  Per wave and chunk of 2 channels that is 36 MFMAs
+// against ~30 LDS fragment reads and ~40 transform instructions (the first version of this kernel transformed
+// the patch in the lane that fed it to the MFMA: 7 non-MFMA instructions per MFMA, 55 % pipe utilisation).
+//
+// Pipeline per chunk k (ONE barrier): U(k+1) and the raw input rows of chunk k+3 are in flight as LDS-DMA
+// (buffer loads with hardware range checks: zero padding, ragged blocks and channels >= K cost no instruction),
+// the V transform of chunk k+1 is scheduled between the MFMAs of chunk k, fragments are double-buffered per kz.
+// Epilogue: the 16 transform points of an output live in 8 waves; each wave reduces its pair along x, the partial
+// sums go through LDS (conflict-free swizzle) and are added in a fixed order (deterministic), then bias /
+// activation / gate / unshuffle / virtual-concat stores as before, 128 contiguous bytes per 16 lanes.
 #include "sr3d_common.h"
 
 #include <limits.h>
@@ -27,17 +32,24 @@
 
 namespace {
 
-constexpr int WKC = 4;                 // input channels per chunk
-constexpr int WHZ = 6, WHY = 6, WHX = 34;
-constexpr int WHCH = WHZ * WHY * WHX;  // halo floats per channel (1224)
-constexpr int WHS = WKC * WHCH;        // 4896 floats
-constexpr int WUS = 3 * 16 * WKC * 32; // 6144 floats: [kz][xi][kc][32 rows]
-constexpr int WNT = 512;               // threads per workgroup
-constexpr int WNI = (WHCH + WNT - 1) / WNT;
-constexpr size_t kWinoLds = (size_t)2 * (WHS + WUS) * 4;
+constexpr int WKC = 2;                      // input channels per chunk
+constexpr int WPL = 3;                      // output planes per workgroup
+constexpr int WVP = WPL + 2;                // input planes per workgroup
+constexpr int WHY = 6, WHX = 34;            // halo rows x columns of one plane
+constexpr int WRE = WVP * WHY * WHX;        // 1020 raw floats per channel
+constexpr int WRC = 1056;                   // raw channel pitch (== 32 mod 64: the two channels use disjoint banks)
+constexpr int WRB = WKC * WRC;              // raw buffer
+constexpr int WVB = WVP * 16 * WKC * 32;    // V buffer [plane][xi][c][tile]
+constexpr int WUS = 3 * 16 * 2 * WKC * 32;  // U buffer [kz][xi][row tile][c][32 rows] = one packed image piece
+constexpr int WNT = 512;
+constexpr int WXB = 8 * 2 * 1024;           // epilogue exchange buffer [wave][value][32 rows x 32 tiles]
+constexpr int kWinoLdsFloats = (2 * WVB + 2 * WUS + 3 * WRB) > 2 * WXB ? (2 * WVB + 2 * WUS + 3 * WRB) : 2 * WXB;
+constexpr size_t kWinoLds = (size_t)kWinoLdsFloats * 4;
+static_assert(kWinoLds <= 160 * 1024, "LDS budget");
 
 typedef const __attribute__((address_space(1))) float* gfloat_p;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_p;
 
 __device__ __forceinline__ float wact(float v, int act) {
   if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -47,8 +59,9 @@ __device__ __forceinline__ float wact(float v, int act) {
 
 __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Hs0 = lds;
-  float* Us0 = lds + 2 * WHS;
+  float* Vs = lds;                 // 2 buffers
+  float* Us = lds + 2 * WVB;       // 2 buffers
+  float* Rs = Us + 2 * WUS;        // 3 buffers
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,250 +80,269 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const int tiy = blk % p.nty;
   const int tiz = blk / p.nty;
   const int b = blockIdx.y;
-  const int z0 = tiz * 4, y0 = tiy * 4, x0 = tix * 32;
+  const int z0 = tiz * WPL, y0 = tiy * 4, x0 = tix * 32;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
+  const int chan_bytes = (int)(ZYX * 4);
 
-  // spatial offsets of this thread's halo elements; -1 = outside the grid (zero padding)
-  int hoff[WNI];
+  // ---- raw rows: LDS-DMA, lane i of a wave instruction lands at dst + 4 i.  Wave w covers elements
+  // [64 (w + 8 i), +64) of a channel's [plane][row][col] halo, i = 0, 1; byte offsets are fixed for the block.
+  unsigned roff[2];
 #pragma unroll
-  for (int i = 0; i < WNI; i++) {
-    const int e = tid + i * WNT;
-    const int hz = e / (WHY * WHX), r2 = e - hz * (WHY * WHX);
+  for (int i = 0; i < 2; i++) {
+    const int e = (wave + 8 * i) * 64 + lane;
+    const int pl = e / (WHY * WHX), r2 = e - pl * (WHY * WHX);
     const int hy = r2 / WHX, hx = r2 - hy * WHX;
-    const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    const bool ok = e < WHCH && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y &&
-                    (unsigned)gx < (unsigned)p.X;
-    hoff[i] = ok ? (gz * p.Y + gy) * p.X + gx : -1;
+    const int gz = z0 - 1 + pl, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool ok = e < WRE && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
+    roff[i] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
   }
-
-  const int plane = wave & 3, half = wave >> 2;   // z plane of the block; xi rows {2*half, 2*half+1}
-  f32x16 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-  const int t = lane & 31, ty = t >> 4, tx = t & 15;
-  const int hb = (lane >> 5) * WHCH + (plane * WHY + 2 * ty) * WHX + 2 * tx;  // this lane's patch origin
-  const int ub = (lane >> 5) * 32 + (lane & 31) + half * (8 * WKC * 32);
-
-  // Branch-free halo prefetch (so that it can be scheduled between MFMAs): out-of-grid elements and channels
-  // beyond K load a valid dummy address and are zeroed by a select.
-  float hv[WKC][WNI];
-  int hclamp[WNI];
-#pragma unroll
-  for (int i = 0; i < WNI; i++) hclamp[i] = hoff[i] >= 0 ? hoff[i] : 0;
-  const gfloat_p dummy = (gfloat_p)p.in.ptr[0];
-  auto load_halo = [&](const int chunk) {
+  auto dma_raw = [&](const int chunk, float* R) {
 #pragma unroll
     for (int c = 0; c < WKC; c++) {
-      const int gc = chunk * WKC + c;  // wave-uniform
-      const bool cok = gc < p.K;
-      gfloat_p base = dummy;
-      if (cok) {
+      const int gc = chunk * WKC + c;   // wave-uniform
+      gfloat_p base = nullptr;
+      if (gc < p.K) {
         const int si = cat_find(p.in, gc);
         base = (gfloat_p)cat_ptr(p.in, si) + ((long long)b * cat_bstride(p.in, si) + (long long)(gc - cat_cbeg(p.in, si)) * ZYX);
       }
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < WNI; i++) hv[c][i] = base[hclamp[i]];   // masked when written to LDS (no wait here)
-    }
-  };
-  auto store_halo = [&](float* H, const int chunk) {
-#pragma unroll
-    for (int c = 0; c < WKC; c++) {
-      const bool cok = chunk * WKC + c < p.K;
-#pragma unroll
-      for (int i = 0; i < WNI; i++)
-        if (tid + i * WNT < WHCH) H[c * WHCH + tid + i * WNT] = (cok && hoff[i] >= 0) ? hv[c][i] : 0.f;
+      for (int i = 0; i < 2; i++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)(R + c * WRC + (wave + 8 * i) * 64), 4, roff[i], 0, 0, 0);
     }
   };
   auto dma_u = [&](const int chunk, float* U) {
-    const float* gw = p.up + (size_t)(nblk * p.nchunks + chunk) * WUS;
-    constexpr int NINSTR = WUS / 256;  // 24 pieces of 1 KiB
-    for (int i = wave; i < NINSTR; i += 8)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
-                                       (__attribute__((address_space(3))) void*)(U + i * 256), 16, 0, 0);
+    const int ch = chunk < p.nchunks ? chunk : p.nchunks - 1;   // past the end: re-read the last piece (never used)
+    const float* gw = p.up + (size_t)(nblk * p.nchunks + ch) * WUS;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + (wave + 8 * i) * 256 + lane * 4),
+                                       (lds_p)(U + (wave + 8 * i) * 256), 16, 0, 0);
   };
 
-  // one k-step = (kz, channel pair): this lane's A fragments (U, from LDS) and B fragments (transformed patch)
-  auto fetch = [&](const float* H, const float* U, const int ks, float (&u)[8], float (&vv)[8]) {
-    const int kz = ks / (WKC / 2), cp = ks % (WKC / 2);
-    const float* hp = H + hb + (2 * cp) * WHCH + kz * (WHY * WHX);
-    float d[4][4];
+  // ---- V transform, half a patch per thread: item q = (plane, half) is wave-uniform, lanes = (tile row, channel,
+  // tile column).  half 0 produces xi_x = 0, 1 from patch columns 0, 1, 2; half 1 xi_x = 2, 3 from columns 2, 3, 1.
+  const int tty = lane >> 5, tch = (lane >> 4) & 1, ttx = lane & 15;
+  const int t_rd = tch * WRC + (2 * tty) * WHX + 2 * ttx;
+  const int t_wr = tch * 32 + tty * 16 + ttx;
+  float vt[4][2];
+  auto tv_read = [&](const float* R, const int q) {
+    const int pl = q >> 1, h = q & 1;
+    const float sgn = h ? -1.f : 1.f;
+    const float* rp = R + t_rd + pl * (WHY * WHX);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const f32x2 a = *reinterpret_cast<const f32x2*>(hp + i * WHX);
-      const f32x2 c2 = *reinterpret_cast<const f32x2*>(hp + i * WHX + 2);
-      d[i][0] = a.x, d[i][1] = a.y, d[i][2] = c2.x, d[i][3] = c2.y;
+      const f32x2 pq = *reinterpret_cast<const f32x2*>(rp + i * WHX + (h ? 2 : 0));
+      const float r = rp[i * WHX + (h ? 1 : 2)];
+      vt[i][0] = pq.x - r;
+      vt[i][1] = fmaf(pq.y, sgn, r);
     }
-    float tt[4][4];
+  };
+  auto tv_write = [&](float* V, const int q) {
+    const int pl = q >> 1, h = q & 1;
+    float* o = V + ((pl * 16 + 2 * h) * WKC) * 32 + t_wr;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {   // along x:  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-      tt[i][0] = d[i][0] - d[i][2];
-      tt[i][1] = d[i][1] + d[i][2];
-      tt[i][2] = d[i][2] - d[i][1];
-      tt[i][3] = d[i][1] - d[i][3];
+    for (int jj = 0; jj < 2; jj++) {
+      o[(0 * 4 + jj) * (WKC * 32)] = vt[0][jj] - vt[2][jj];
+      o[(1 * 4 + jj) * (WKC * 32)] = vt[1][jj] + vt[2][jj];
+      o[(2 * 4 + jj) * (WKC * 32)] = vt[2][jj] - vt[1][jj];
+      o[(3 * 4 + jj) * (WKC * 32)] = vt[1][jj] - vt[3][jj];
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {   // along y: only this wave's two rows of B^T
-      vv[j] = half == 0 ? tt[0][j] - tt[2][j] : tt[2][j] - tt[1][j];
-      vv[4 + j] = half == 0 ? tt[1][j] + tt[2][j] : tt[1][j] - tt[3][j];
-    }
-
-    const float* up = U + ((kz * 16) * WKC + 2 * cp) * 32 + ub;
-#pragma unroll
-    for (int q = 0; q < 8; q++) u[q] = up[q * (WKC * 32)];
   };
 
-  // ---- prologue: chunk 0
-  load_halo(0);
-  dma_u(0, Us0);
-  store_halo(Hs0, 0);
+  f32x16 acc[12];   // [(rt * 3 + plane) * 2 + xl]
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-  constexpr int KSTEPS = 3 * (WKC / 2);
-  for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    const int cur = chunk & 1;
-    const float* H = Hs0 + cur * WHS;
-    const float* U = Us0 + cur * WUS;
-    __syncthreads();  // buffers `cur` are complete (the compiler drains vmcnt here); buffers `cur^1` are free
-    const bool more = chunk + 1 < p.nchunks;
-    if (more) dma_u(chunk + 1, Us0 + (cur ^ 1) * WUS);    // straight into the other weight buffer
-    // The fetch of k-step s+1 (8 ds_read_b64 + 16 ds_read_b32 + ~40 VALU) is interleaved with the 16 MFMAs
-    // of k-step s: an MFMA occupies the matrix pipe for 64 cycles but the issue port only for 8, and with one
-    // wave per SIMD nobody else would use the gaps.  sched_group_barrier pins "1 MFMA, 2 LDS reads, 3 VALU".
-    float u0[8], v0[8], u1[8], v1[8];
-    fetch(H, U, 0, u0, v0);
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks += 2) {
-      fetch(H, U, ks + 1, u1, v1);
-      if (ks == 0) load_halo(more ? chunk + 1 : chunk);   // next chunk's raw input -> registers (the last chunk
-                                                          // re-reads its own: harmless and keeps this branch-free)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[q], v0[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks + 2 < KSTEPS) fetch(H, U, ks + 2, u0, v0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[q], v1[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) store_halo(Hs0 + (cur ^ 1) * WHS, chunk + 1);
+  // ---- prologue: raw rows of chunks 0..2, U(0); V(0)
+  dma_u(0, Us);
+  dma_raw(0, Rs);
+  dma_raw(1, Rs + WRB);
+  dma_raw(2, Rs + 2 * WRB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  tv_read(Rs, wave);
+  tv_write(Vs, wave);
+  if (wave < 2) {
+    tv_read(Rs, wave + 8);
+    tv_write(Vs, wave + 8);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: Y = A^T M A.  Each wave transforms its two xi rows; the partial results of the upper half
-  // (waves 4..7) go through LDS to the lower half, which adds its own, applies bias / activation / gate and stores.
-  float part[16][2][2];   // [element][yo][xo]
+  const int fu = 2 * wave * (2 * WKC * 32) + lane;   // xi = 2 * wave: A fragments  [kz][xi][rt][c][32]
+  const int fv = 2 * wave * (WKC * 32) + lane;       //                 B fragments  [plane][xi][c][32]
+  int rb = 0;   // raw buffer of chunk k
+  for (int k = 0; k < p.nchunks; k++) {
+    const int cur = k & 1;
+    const int rb1 = rb == 2 ? 0 : rb + 1;
+    dma_u(k + 1, Us + (cur ^ 1) * WUS);
+    dma_raw(k + 3, Rs + rb * WRB);          // chunk k's raw buffer is free (its V was made during chunk k-1)
+    const float* U = Us + cur * WUS + fu;
+    const float* V = Vs + cur * WVB + fv;
+    const float* Rn = Rs + rb1 * WRB;       // raw rows of chunk k+1
+    float* Vn = Vs + (cur ^ 1) * WVB;
+    float a[2][2][2], bq[2][3][2];          // [set][xl][rt], [set][plane][xl]
+    auto frags = [&](const int kz, const int set) {
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    float s[2][2];        // rows (this wave's xi_y = 2*half + r) after the x transform A^T = [1 1 1 0; 0 1 -1 -1]
+      for (int xl = 0; xl < 2; xl++) {
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      s[r][0] = acc[r * 4 + 0][e] + acc[r * 4 + 1][e] + acc[r * 4 + 2][e];
-      s[r][1] = acc[r * 4 + 1][e] - acc[r * 4 + 2][e] - acc[r * 4 + 3][e];
+        for (int rt = 0; rt < 2; rt++) a[set][xl][rt] = U[((kz * 16 + xl) * 2 + rt) * (WKC * 32)];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) bq[set][pl][xl] = V[((pl + kz) * 16 + xl) * (WKC * 32)];
+      }
+    };
+    auto mfmas = [&](const int set) {
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+          for (int xl = 0; xl < 2; xl++)
+            acc[(rt * 3 + pl) * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                a[set][xl][rt], bq[set][pl][xl], acc[(rt * 3 + pl) * 2 + xl], 0, 0, 0);
+    };
+    frags(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(1, 1);
+    tv_read(Rn, wave);
+    mfmas(0);
+    tv_write(Vn, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(2, 0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 2) {
+      tv_read(Rn, wave + 8);
+      tv_write(Vn, wave + 8);
     }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      // y transform: rows 0,1 contribute (m0 + m1, m1); rows 2,3 contribute (m2, -m2 - m3)
-      part[e][0][j] = half == 0 ? s[0][j] + s[1][j] : s[0][j];
-      part[e][1][j] = half == 0 ? s[1][j] : -s[0][j] - s[1][j];
-    }
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // U(k+1) and everything older has landed; the 4 raw-row loads of chunk k+3 may stay in flight
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rb = rb1;
   }
-  __syncthreads();   // all MFMA phases are done: the staging buffers can carry the exchange
-  float* X = lds + (plane * 64 + lane) * 65;   // 64 floats per lane, odd pitch
-  if (half == 1) {
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) X[e * 4 + q] = part[e][q >> 1][q & 1];
-  }
-  __syncthreads();
-  if (half == 1) return;
-#pragma unroll
-  for (int e = 0; e < 16; e++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) part[e][q >> 1][q & 1] += X[e * 4 + q];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray prefetches must not land in the exchange buffers
+  __builtin_amdgcn_s_barrier();
 
-  const int oz = z0 + plane;
-  if (oz >= p.Z) return;
-  const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+  // ---- epilogue: Y = A^T M A with A^T = [1 1 1 0; 0 1 -1 -1].  Wave w holds xi_y = w >> 1 and the xi_x pair
+  // (w & 1): it reduces its pair along x (2 values per element), the 8 waves' values meet in LDS.
+  const int xh = wave & 1;
+  const int er = tid >> 5, et = tid & 31;              // reader: rows er, er + 16 of the 32-row tile, tile et
+  const int ety = et >> 4, etx = et & 15;
+  const int oy = y0 + 2 * ety, ox = x0 + 2 * etx;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
-  const int row0 = p.n_off + nblk * 32 + 4 * (lane >> 5);
   const bool pair_ok = (p.TX_ & 1) == 0 && p.pair_aligned;   // (x, x+1) pairs are 8-byte aligned in every destination
-
+  int round = 0;
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    // gated: element e < 8 is the feature row, e + 8 the gate row of the same channel
-    if (p.epi == SR3D_EPI_GATED && e >= 8) break;
-    const int rl = (e & 3) + 8 * (e >> 2);  // row inside the 32-row block (before + 4*(lane>>5))
-    if (p.epi == SR3D_EPI_GATED) {
-      const int co = (p.n_off + nblk * 32) / 2 + 4 * (lane >> 5) + rl;  // 16 channels per row block
-      if (co >= p.Cg) continue;
-      const float bf = p.bias ? p.bias[co] : 0.f, bg = p.bias2 ? p.bias2[co] : 0.f;
-      const int eg = e + 8 < 16 ? e + 8 : e;
+  for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-      for (int yo = 0; yo < 2; yo++) {
-        if (oy + yo >= p.Y) continue;
-        float f[2], sg[2];
+    for (int pl = 0; pl < 3; pl++, round++) {
+      float* X = lds + (round & 1) * WXB;
+      {
+        float* xw = X + wave * 2048;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const float m0 = acc[(rt * 3 + pl) * 2][e], m1 = acc[(rt * 3 + pl) * 2 + 1][e];
+          const float s0 = xh ? m0 : m0 + m1;
+          const float s1 = xh ? -m0 - m1 : m1;
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int o = (row * 32 + (lane & 31)) ^ (((row >> 2) & 1) << 5);
+          xw[o] = s0, xw[1024 + o] = s1;
+        }
+      }
+      __syncthreads();
+      float yv[2][2][2];   // [row half][yo][xo]
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int row = er + 16 * hh;
+        const int o = (row * 32 + et) ^ (((row >> 2) & 1) << 5);
 #pragma unroll
         for (int xo = 0; xo < 2; xo++) {
-          f[xo] = wact(part[e][yo][xo] + bf, p.act);
-          sg[xo] = 1.f / (1.f + expf(-(part[eg][yo][xo] + bg)));
-        }
-        const long long o = ((long long)b * p.Cg + co) * TZYX + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
-        if (pair_ok && ox + 1 < p.X) {   // both voxels of the tile row: one 8-byte store per tensor
-          *reinterpret_cast<f32x2*>(p.y + o) = f32x2{sg[0] * f[0], sg[1] * f[1]};
-          if (p.save_f) {
-            *reinterpret_cast<f32x2*>(p.save_f + o) = f32x2{f[0], f[1]};
-            *reinterpret_cast<f32x2*>(p.save_s + o) = f32x2{sg[0], sg[1]};
-          }
-        } else {
+          float s[4];
 #pragma unroll
-          for (int xo = 0; xo < 2; xo++) {
-            if (ox + xo >= p.X) continue;
-            p.y[o + xo] = sg[xo] * f[xo];
-            if (p.save_f) p.save_f[o + xo] = f[xo], p.save_s[o + xo] = sg[xo];
-          }
+          for (int xy = 0; xy < 4; xy++) s[xy] = X[(2 * xy) * 2048 + xo * 1024 + o] + X[(2 * xy + 1) * 2048 + xo * 1024 + o];
+          yv[hh][0][xo] = (s[0] + s[1]) + s[2];
+          yv[hh][1][xo] = (s[1] - s[2]) - s[3];
         }
       }
-    } else {
-      const int n = row0 + rl;
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      if (p.epi == SR3D_EPI_UNSHUFFLE) {
-        const int f = n / p.unsh_C, c = n - f * p.unsh_C;
-        float* base = p.y + ((long long)b * p.unsh_C + c) * TZYX;
+      const int oz = z0 + pl;
+      if (oz >= p.Z) continue;   // (wave-uniform; the barrier above has been passed by everyone)
+      const int rbase = p.n_off + nblk * 64 + rt * 32;
+      if (p.epi == SR3D_EPI_GATED) {
+        const int co = rbase / 2 + er;   // 16 channels per 32-row tile: rows 0..15 features, 16..31 gates
+        if (co < p.Cg) {
+          const float bf = p.bias ? p.bias[co] : 0.f, bg = p.bias2 ? p.bias2[co] : 0.f;
 #pragma unroll
-        for (int yo = 0; yo < 2; yo++)
+          for (int yo = 0; yo < 2; yo++) {
+            if (oy + yo >= p.Y) continue;
+            float f[2], sg[2];
 #pragma unroll
-          for (int xo = 0; xo < 2; xo++) {
-            if (oy + yo >= p.Y || ox + xo >= p.X) continue;
-            base[((long long)(2 * oz + (f >> 2)) * p.TY_ + 2 * (oy + yo) + ((f >> 1) & 1)) * p.TX_ + 2 * (ox + xo) + (f & 1)] =
-                wact(part[e][yo][xo] + bv, p.act);
+            for (int xo = 0; xo < 2; xo++) {
+              f[xo] = wact(yv[0][yo][xo] + bf, p.act);
+              sg[xo] = 1.f / (1.f + expf(-(yv[1][yo][xo] + bg)));
+            }
+            const long long o = ((long long)b * p.Cg + co) * TZYX + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
+            if (pair_ok && ox + 1 < p.X) {
+              *reinterpret_cast<f32x2*>(p.y + o) = f32x2{sg[0] * f[0], sg[1] * f[1]};
+              if (p.save_f) {
+                *reinterpret_cast<f32x2*>(p.save_f + o) = f32x2{f[0], f[1]};
+                *reinterpret_cast<f32x2*>(p.save_s + o) = f32x2{sg[0], sg[1]};
+              }
+            } else {
+#pragma unroll
+              for (int xo = 0; xo < 2; xo++) {
+                if (ox + xo >= p.X) continue;
+                p.y[o + xo] = sg[xo] * f[xo];
+                if (p.save_f) p.save_f[o + xo] = f[xo], p.save_s[o + xo] = sg[xo];
+              }
+            }
           }
+        }
       } else {
-        const int si = cat_find(p.out, n);
-        float* base = cat_ptr(p.out, si);
-        if (base == nullptr) continue;
-        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
 #pragma unroll
-        for (int yo = 0; yo < 2; yo++) {
-          if (oy + yo >= p.Y) continue;
-          float* o = base + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
-          const float r0 = wact(part[e][yo][0] + bv, p.act), r1 = wact(part[e][yo][1] + bv, p.act);
-          if (pair_ok && ox + 1 < p.X) {
-            *reinterpret_cast<f32x2*>(o) = f32x2{r0, r1};
+        for (int hh = 0; hh < 2; hh++) {
+          const int n = rbase + er + 16 * hh;
+          if (n >= p.N) continue;
+          const float bv = p.bias ? p.bias[n] : 0.f;
+          if (p.epi == SR3D_EPI_UNSHUFFLE) {
+            const int f = n / p.unsh_C, c = n - f * p.unsh_C;
+            float* base = p.y + ((long long)b * p.unsh_C + c) * TZYX;
+#pragma unroll
+            for (int yo = 0; yo < 2; yo++)
+#pragma unroll
+              for (int xo = 0; xo < 2; xo++) {
+                if (oy + yo >= p.Y || ox + xo >= p.X) continue;
+                base[((long long)(2 * oz + (f >> 2)) * p.TY_ + 2 * (oy + yo) + ((f >> 1) & 1)) * p.TX_ + 2 * (ox + xo) + (f & 1)] =
+                    wact(yv[hh][yo][xo] + bv, p.act);
+              }
           } else {
-            if (ox < p.X) o[0] = r0;
-            if (ox + 1 < p.X) o[1] = r1;
+            const int si = cat_find(p.out, n);
+            float* base = cat_ptr(p.out, si);
+            if (base == nullptr) continue;
+            base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+#pragma unroll
+            for (int yo = 0; yo < 2; yo++) {
+              if (oy + yo >= p.Y) continue;
+              float* o = base + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
+              const float r0 = wact(yv[hh][yo][0] + bv, p.act), r1 = wact(yv[hh][yo][1] + bv, p.act);
+              if (pair_ok && ox + 1 < p.X) {
+                *reinterpret_cast<f32x2*>(o) = f32x2{r0, r1};
+              } else {
+                if (ox < p.X) o[0] = r0;
+                if (ox + 1 < p.X) o[1] = r1;
+              }
+            }
           }
         }
       }
     }
-  }
 }
 
-// ---- weight transform + packing: image [nblk][chunk][kz][xi][kc][32 rows]
+// ---- weight transform + packing: image [row block of 64][chunk][kz][xi][row tile][c][32 rows]
 struct WinoPackParams {
   const float* w1;
   const float* w2;
@@ -330,13 +362,15 @@ __global__ void wino_pack_kernel(const WinoPackParams p) {
     r /= 32;
     const int kc = r % WKC;
     r /= WKC;
+    const int rt = r % 2;
+    r /= 2;
     const int xi = r % 16;
     r /= 16;
     const int kz = r % 3;
     r /= 3;
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
-    const int n = nb * 32 + rr, k = chunk * WKC + kc;
+    const int n = nb * 64 + rt * 32 + rr, k = chunk * WKC + kc;
     float val = 0.f;
     if (n < p.N && k < p.K) {
       const float* w = nullptr;  // -> w[co][ci][0][0][0]
@@ -344,7 +378,7 @@ __global__ void wino_pack_kernel(const WinoPackParams p) {
       if (p.kind == SR3D_PACK_FWD) {
         w = p.w1 + ((long long)n * p.Cin + k) * 27;
       } else if (p.kind == SR3D_PACK_FWD_GATED) {
-        const int co = (n >> 5) * 16 + (n & 15);  // rows 0..15 of a block: features, 16..31: gates
+        const int co = (n >> 5) * 16 + (n & 15);  // rows 0..15 of a 32-row tile: features, 16..31: gates
         if (co < p.Cout) w = ((n & 16) ? p.w2 : p.w1) + ((long long)co * p.Cin + k) * 27;
       } else {  // input gradient: rows = input channels that need a gradient, K = output channels, taps mirrored
         const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
@@ -375,14 +409,14 @@ bool sr3d_wino_enabled() {
   return on;
 }
 
-size_t sr3d_wino_image_floats(int rows, int K) { return (size_t)ceil_div(rows, 32) * ceil_div(K, WKC) * WUS; }
+size_t sr3d_wino_image_floats(int rows, int K) { return (size_t)ceil_div(rows, 64) * ceil_div(K, WKC) * WUS; }
 
 int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                    const int* cbeg, float* image, hipStream_t st) {
   WinoPackParams p{};
   p.w1 = w1, p.w2 = w2, p.up = image;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows;
-  p.nchunks = ceil_div(K, WKC), p.nblk = ceil_div(rows, 32);
+  p.nchunks = ceil_div(K, WKC), p.nblk = ceil_div(rows, 64);
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
   for (int i = 0; i < SR3D_MAX_SRC; i++) p.cbeg[i] = cbeg ? cbeg[i] : 0;
   const long long total = (long long)p.nblk * p.nchunks * WUS;
@@ -393,8 +427,8 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
 }
 
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
-  p.ntz = ceil_div(p.Z, 4), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
-  p.nblk = ceil_div(p.N, 32);
+  p.ntz = ceil_div(p.Z, WPL), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
+  p.nblk = ceil_div(p.N, 64);
   p.nchunks = ceil_div(p.K, WKC);
   {
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.save_f) | reinterpret_cast<uintptr_t>(p.save_s);
@@ -403,6 +437,7 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   }
   const long long nwg = (long long)p.ntz * p.nty * p.ntx * p.nblk;
   SR3D_CHECK(nwg < (1ll << 31) && B <= 65535, SR3D_E_ARG, "winograd conv: grid too large");
+  SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "winograd conv: more than 2^29 voxels per channel");
   static thread_local bool configured = false;
   if (!configured) {
     SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
