@@ -30,6 +30,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int WKC = 2;                      // input channels per chunk
@@ -100,11 +102,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
 #pragma unroll
     for (int c = 0; c < WKC; c++) {
       const int gc = chunk * WKC + c;   // wave-uniform
-      gfloat_p base = nullptr;
-      if (gc < p.K) {
-        const int si = cat_find(p.in, gc);
-        base = (gfloat_p)cat_ptr(p.in, si) + ((long long)b * cat_bstride(p.in, si) + (long long)(gc - cat_cbeg(p.in, si)) * ZYX);
-      }
+      const int gcc = gc < p.K ? gc : p.K - 1;   // branch-free: channels past the end get an empty descriptor
+      const int si = cat_find(p.in, gcc);
+      const gfloat_p base =
+          (gfloat_p)cat_ptr(p.in, si) + ((long long)b * cat_bstride(p.in, si) + (long long)(gcc - cat_cbeg(p.in, si)) * ZYX);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -174,55 +175,59 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
 
   const int fu = 2 * wave * (2 * WKC * 32) + lane;   // xi = 2 * wave: A fragments  [kz][xi][rt][c][32]
   const int fv = 2 * wave * (WKC * 32) + lane;       //                 B fragments  [plane][xi][c][32]
+  float a[3][2][2], bq[3][3][2];                     // fragment sets (one per kz): [set][xl][rt], [set][plane][xl]
+  auto frags = [&](const float* U, const float* V, const int kz, const int set) {
+#pragma unroll
+    for (int xl = 0; xl < 2; xl++) {
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++) a[set][xl][rt] = U[((kz * 16 + xl) * 2 + rt) * (WKC * 32)];
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) bq[set][pl][xl] = V[((pl + kz) * 16 + xl) * (WKC * 32)];
+    }
+  };
+  auto mfmas = [&](const int set) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+        for (int xl = 0; xl < 2; xl++)
+          acc[(rt * 3 + pl) * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][xl][rt], bq[set][pl][xl],
+                                                                             acc[(rt * 3 + pl) * 2 + xl], 0, 0, 0);
+  };
   int rb = 0;   // raw buffer of chunk k
+  // One chunk per iteration.  Its kz = 0 fragments are already in set 0 (prefetched).  The single barrier sits
+  // BEFORE the last MFMA group: by then every wave has read chunk k's fragments into registers and written its
+  // share of V(k+1), so the last 12 MFMAs run while the next chunk's first fragments are fetched and the loop
+  // turns around.
+  frags(Us + fu, Vs + fv, 0, 0);
   for (int k = 0; k < p.nchunks; k++) {
     const int cur = k & 1;
     const int rb1 = rb == 2 ? 0 : rb + 1;
-    dma_u(k + 1, Us + (cur ^ 1) * WUS);
-    dma_raw(k + 3, Rs + rb * WRB);          // chunk k's raw buffer is free (its V was made during chunk k-1)
     const float* U = Us + cur * WUS + fu;
     const float* V = Vs + cur * WVB + fv;
     const float* Rn = Rs + rb1 * WRB;       // raw rows of chunk k+1
     float* Vn = Vs + (cur ^ 1) * WVB;
-    float a[2][2][2], bq[2][3][2];          // [set][xl][rt], [set][plane][xl]
-    auto frags = [&](const int kz, const int set) {
-#pragma unroll
-      for (int xl = 0; xl < 2; xl++) {
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++) a[set][xl][rt] = U[((kz * 16 + xl) * 2 + rt) * (WKC * 32)];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) bq[set][pl][xl] = V[((pl + kz) * 16 + xl) * (WKC * 32)];
-      }
-    };
-    auto mfmas = [&](const int set) {
-#pragma unroll
-      for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-#pragma unroll
-          for (int xl = 0; xl < 2; xl++)
-            acc[(rt * 3 + pl) * 2 + xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                a[set][xl][rt], bq[set][pl][xl], acc[(rt * 3 + pl) * 2 + xl], 0, 0, 0);
-    };
-    frags(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    frags(1, 1);
+    frags(U, V, 1, 1);
     tv_read(Rn, wave);
+    dma_u(k + 1, Us + (cur ^ 1) * WUS);
+    dma_raw(k + 3, Rs + rb * WRB);          // chunk k's raw buffer is free (its V was made during chunk k-1)
     mfmas(0);
     tv_write(Vn, wave);
     __builtin_amdgcn_sched_barrier(0);
-    frags(2, 0);
+    frags(U, V, 2, 2);
     mfmas(1);
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 2) {
       tv_read(Rn, wave + 8);
       tv_write(Vn, wave + 8);
     }
-    mfmas(0);
-    __builtin_amdgcn_sched_barrier(0);
     // U(k+1) and everything older has landed; the 4 raw-row loads of chunk k+3 may stay in flight
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    frags(Us + (cur ^ 1) * WUS + fu, Vn + fv, 0, 0);   // chunk k+1, kz = 0
+    mfmas(2);
+    __builtin_amdgcn_sched_barrier(0);
     rb = rb1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray prefetches must not land in the exchange buffers
@@ -236,6 +241,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const int oy = y0 + 2 * ety, ox = x0 + 2 * etx;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
   const bool pair_ok = (p.TX_ & 1) == 0 && p.pair_aligned;   // (x, x+1) pairs are 8-byte aligned in every destination
+  // biases of this thread's rows: loaded once, before the rounds (a load inside a round would expose its latency 6x)
+  float ebias[2][2];   // [rt][row half]; gated: [rt][0] = feature bias, [rt][1] = gate bias
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++) {
+    const int rbase = p.n_off + nblk * 64 + rt * 32;
+    if (p.epi == SR3D_EPI_GATED) {
+      const int co = rbase / 2 + er;
+      ebias[rt][0] = (p.bias && co < p.Cg) ? p.bias[co] : 0.f;
+      ebias[rt][1] = (p.bias2 && co < p.Cg) ? p.bias2[co] : 0.f;
+    } else {
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int n = rbase + er + 16 * hh;
+        ebias[rt][hh] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+    }
+  }
   int round = 0;
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
       if (p.epi == SR3D_EPI_GATED) {
         const int co = rbase / 2 + er;   // 16 channels per 32-row tile: rows 0..15 features, 16..31 gates
         if (co < p.Cg) {
-          const float bf = p.bias ? p.bias[co] : 0.f, bg = p.bias2 ? p.bias2[co] : 0.f;
+          const float bf = ebias[rt][0], bg = ebias[rt][1];
 #pragma unroll
           for (int yo = 0; yo < 2; yo++) {
             if (oy + yo >= p.Y) continue;
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
         for (int hh = 0; hh < 2; hh++) {
           const int n = rbase + er + 16 * hh;
           if (n >= p.N) continue;
-          const float bv = p.bias ? p.bias[n] : 0.f;
+          const float bv = ebias[rt][hh];
           if (p.epi == SR3D_EPI_UNSHUFFLE) {
             const int f = n / p.unsh_C, c = n - f * p.unsh_C;
             float* base = p.y + ((long long)b * p.unsh_C + c) * TZYX;
