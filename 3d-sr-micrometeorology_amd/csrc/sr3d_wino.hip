@@ -241,23 +241,44 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const int oy = y0 + 2 * ety, ox = x0 + 2 * etx;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
   const bool pair_ok = (p.TX_ & 1) == 0 && p.pair_aligned;   // (x, x+1) pairs are 8-byte aligned in every destination
-  // biases of this thread's rows: loaded once, before the rounds (a load inside a round would expose its latency 6x)
-  float ebias[2][2];   // [rt][row half]; gated: [rt][0] = feature bias, [rt][1] = gate bias
+  // Destinations and biases of this thread's rows are worked out ONCE (64-bit address arithmetic and the bias
+  // loads would otherwise be repeated, latency exposed, in each of the 6 rounds).
+  float ebias[2][2];    // [rt][row half]; gated: [rt][0] = feature bias, [rt][1] = gate bias
+  float* eptr[2][2];    // voxel (z0, oy, ox) of the row's destination; nullptr = nothing to store
+  const bool unsh = p.epi == SR3D_EPI_UNSHUFFLE;
+  const long long pstride = (long long)p.TY_ * p.TX_ * (unsh ? 2 : 1);   // one output plane further
+  const int ystride = unsh ? 2 * p.TX_ : p.TX_, xstride = unsh ? 2 : 1;
 #pragma unroll
   for (int rt = 0; rt < 2; rt++) {
     const int rbase = p.n_off + nblk * 64 + rt * 32;
-    if (p.epi == SR3D_EPI_GATED) {
-      const int co = rbase / 2 + er;
-      ebias[rt][0] = (p.bias && co < p.Cg) ? p.bias[co] : 0.f;
-      ebias[rt][1] = (p.bias2 && co < p.Cg) ? p.bias2[co] : 0.f;
-    } else {
 #pragma unroll
-      for (int hh = 0; hh < 2; hh++) {
-        const int n = rbase + er + 16 * hh;
-        ebias[rt][hh] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    for (int hh = 0; hh < 2; hh++) {
+      const int n = rbase + er + 16 * hh;
+      ebias[rt][hh] = 0.f, eptr[rt][hh] = nullptr;
+      if (p.epi == SR3D_EPI_GATED) {
+        const int co = rbase / 2 + er;   // 16 channels per 32-row tile: rows 0..15 features, 16..31 gates
+        if (co < p.Cg) {
+          const float* bsrc = hh ? p.bias2 : p.bias;
+          ebias[rt][hh] = bsrc ? bsrc[co] : 0.f;
+          eptr[rt][hh] = p.y + (((long long)b * p.Cg + co) * TZYX + ((long long)z0 * p.TY_ + oy) * p.TX_ + ox);
+        }
+      } else if (n < p.N) {
+        ebias[rt][hh] = p.bias ? p.bias[n] : 0.f;
+        if (unsh) {
+          const int f = n / p.unsh_C, c = n - f * p.unsh_C;
+          eptr[rt][hh] = p.y + (((long long)b * p.unsh_C + c) * TZYX +
+                                ((long long)(2 * z0 + (f >> 2)) * p.TY_ + 2 * oy + ((f >> 1) & 1)) * p.TX_ + 2 * ox + (f & 1));
+        } else {
+          const int si = cat_find(p.out, n);
+          float* base = cat_ptr(p.out, si);
+          if (base != nullptr)
+            eptr[rt][hh] = base + ((long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX +
+                                   ((long long)z0 * p.TY_ + oy) * p.TX_ + ox);
+        }
       }
     }
   }
+  const long long sf_off = p.save_f ? p.save_f - p.y : 0, ss_off = p.save_s ? p.save_s - p.y : 0;
   int round = 0;
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
@@ -291,35 +312,31 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
           yv[hh][1][xo] = (s[1] - s[2]) - s[3];
         }
       }
-      const int oz = z0 + pl;
-      if (oz >= p.Z) continue;   // (wave-uniform; the barrier above has been passed by everyone)
-      const int rbase = p.n_off + nblk * 64 + rt * 32;
+      if (z0 + pl >= p.Z) continue;   // (wave-uniform; the barrier above has been passed by everyone)
       if (p.epi == SR3D_EPI_GATED) {
-        const int co = rbase / 2 + er;   // 16 channels per 32-row tile: rows 0..15 features, 16..31 gates
-        if (co < p.Cg) {
-          const float bf = ebias[rt][0], bg = ebias[rt][1];
+        if (eptr[rt][0] != nullptr) {
 #pragma unroll
           for (int yo = 0; yo < 2; yo++) {
             if (oy + yo >= p.Y) continue;
             float f[2], sg[2];
 #pragma unroll
             for (int xo = 0; xo < 2; xo++) {
-              f[xo] = wact(yv[0][yo][xo] + bf, p.act);
-              sg[xo] = 1.f / (1.f + expf(-(yv[1][yo][xo] + bg)));
+              f[xo] = wact(yv[0][yo][xo] + ebias[rt][0], p.act);
+              sg[xo] = 1.f / (1.f + expf(-(yv[1][yo][xo] + ebias[rt][1])));
             }
-            const long long o = ((long long)b * p.Cg + co) * TZYX + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
+            float* o = eptr[rt][0] + (pl * pstride + yo * ystride);
             if (pair_ok && ox + 1 < p.X) {
-              *reinterpret_cast<f32x2*>(p.y + o) = f32x2{sg[0] * f[0], sg[1] * f[1]};
+              *reinterpret_cast<f32x2*>(o) = f32x2{sg[0] * f[0], sg[1] * f[1]};
               if (p.save_f) {
-                *reinterpret_cast<f32x2*>(p.save_f + o) = f32x2{f[0], f[1]};
-                *reinterpret_cast<f32x2*>(p.save_s + o) = f32x2{sg[0], sg[1]};
+                *reinterpret_cast<f32x2*>(o + sf_off) = f32x2{f[0], f[1]};
+                *reinterpret_cast<f32x2*>(o + ss_off) = f32x2{sg[0], sg[1]};
               }
             } else {
 #pragma unroll
               for (int xo = 0; xo < 2; xo++) {
                 if (ox + xo >= p.X) continue;
-                p.y[o + xo] = sg[xo] * f[xo];
-                if (p.save_f) p.save_f[o + xo] = f[xo], p.save_s[o + xo] = sg[xo];
+                o[xo] = sg[xo] * f[xo];
+                if (p.save_f) o[sf_off + xo] = f[xo], o[ss_off + xo] = sg[xo];
               }
             }
           }
@@ -327,36 +344,18 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
       } else {
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-          const int n = rbase + er + 16 * hh;
-          if (n >= p.N) continue;
+          if (eptr[rt][hh] == nullptr) continue;
           const float bv = ebias[rt][hh];
-          if (p.epi == SR3D_EPI_UNSHUFFLE) {
-            const int f = n / p.unsh_C, c = n - f * p.unsh_C;
-            float* base = p.y + ((long long)b * p.unsh_C + c) * TZYX;
 #pragma unroll
-            for (int yo = 0; yo < 2; yo++)
-#pragma unroll
-              for (int xo = 0; xo < 2; xo++) {
-                if (oy + yo >= p.Y || ox + xo >= p.X) continue;
-                base[((long long)(2 * oz + (f >> 2)) * p.TY_ + 2 * (oy + yo) + ((f >> 1) & 1)) * p.TX_ + 2 * (ox + xo) + (f & 1)] =
-                    wact(yv[hh][yo][xo] + bv, p.act);
-              }
-          } else {
-            const int si = cat_find(p.out, n);
-            float* base = cat_ptr(p.out, si);
-            if (base == nullptr) continue;
-            base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
-#pragma unroll
-            for (int yo = 0; yo < 2; yo++) {
-              if (oy + yo >= p.Y) continue;
-              float* o = base + ((long long)oz * p.TY_ + oy + yo) * p.TX_ + ox;
-              const float r0 = wact(yv[hh][yo][0] + bv, p.act), r1 = wact(yv[hh][yo][1] + bv, p.act);
-              if (pair_ok && ox + 1 < p.X) {
-                *reinterpret_cast<f32x2*>(o) = f32x2{r0, r1};
-              } else {
-                if (ox < p.X) o[0] = r0;
-                if (ox + 1 < p.X) o[1] = r1;
-              }
+          for (int yo = 0; yo < 2; yo++) {
+            if (oy + yo >= p.Y) continue;
+            float* o = eptr[rt][hh] + (pl * pstride + yo * ystride);
+            const float r0 = wact(yv[hh][yo][0] + bv, p.act), r1 = wact(yv[hh][yo][1] + bv, p.act);
+            if (!unsh && pair_ok && ox + 1 < p.X) {
+              *reinterpret_cast<f32x2*>(o) = f32x2{r0, r1};
+            } else {
+              if (ox < p.X) o[0] = r0;
+              if (ox + 1 < p.X) o[xstride] = r1;
             }
           }
         }
