@@ -59,6 +59,7 @@ __device__ __forceinline__ float wact(float v, int act) {
   return v;
 }
 
+template <int NRT>   // 32-row tiles per workgroup: 2, or 1 for a last block with <= 32 rows
 __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Vs = lds;                 // 2 buffers
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nblk = v % p.nblk;
+  const int nblk = p.nb_off + v % p.nblk;   // 64-row block of the layer (index into the packed image)
   int blk = v / p.nblk;
   const int tix = blk % p.ntx;
   blk /= p.ntx;
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
     }
   };
 
-  f32x16 acc[12];   // [(rt * 3 + plane) * 2 + xl]
+  f32x16 acc[6 * NRT];   // [(rt * 3 + plane) * 2 + xl]
 #pragma unroll
-  for (int i = 0; i < 12; i++)
+  for (int i = 0; i < 6 * NRT; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
@@ -175,19 +176,19 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
 
   const int fu = 2 * wave * (2 * WKC * 32) + lane;   // xi = 2 * wave: A fragments  [kz][xi][rt][c][32]
   const int fv = 2 * wave * (WKC * 32) + lane;       //                 B fragments  [plane][xi][c][32]
-  float a[3][2][2], bq[3][3][2];                     // fragment sets (one per kz): [set][xl][rt], [set][plane][xl]
+  float a[3][2][NRT], bq[3][3][2];                     // fragment sets (one per kz): [set][xl][rt], [set][plane][xl]
   auto frags = [&](const float* U, const float* V, const int kz, const int set) {
 #pragma unroll
     for (int xl = 0; xl < 2; xl++) {
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++) a[set][xl][rt] = U[((kz * 16 + xl) * 2 + rt) * (WKC * 32)];
+      for (int rt = 0; rt < NRT; rt++) a[set][xl][rt] = U[((kz * 16 + xl) * 2 + rt) * (WKC * 32)];
 #pragma unroll
       for (int pl = 0; pl < 3; pl++) bq[set][pl][xl] = V[((pl + kz) * 16 + xl) * (WKC * 32)];
     }
   };
   auto mfmas = [&](const int set) {
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
       for (int pl = 0; pl < 3; pl++)
 #pragma unroll
@@ -243,13 +244,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const bool pair_ok = (p.TX_ & 1) == 0 && p.pair_aligned;   // (x, x+1) pairs are 8-byte aligned in every destination
   // Destinations and biases of this thread's rows are worked out ONCE (64-bit address arithmetic and the bias
   // loads would otherwise be repeated, latency exposed, in each of the 6 rounds).
-  float ebias[2][2];    // [rt][row half]; gated: [rt][0] = feature bias, [rt][1] = gate bias
-  float* eptr[2][2];    // voxel (z0, oy, ox) of the row's destination; nullptr = nothing to store
+  float ebias[NRT][2];  // [rt][row half]; gated: [rt][0] = feature bias, [rt][1] = gate bias
+  float* eptr[NRT][2];  // voxel (z0, oy, ox) of the row's destination; nullptr = nothing to store
   const bool unsh = p.epi == SR3D_EPI_UNSHUFFLE;
   const long long pstride = (long long)p.TY_ * p.TX_ * (unsh ? 2 : 1);   // one output plane further
   const int ystride = unsh ? 2 * p.TX_ : p.TX_, xstride = unsh ? 2 : 1;
 #pragma unroll
-  for (int rt = 0; rt < 2; rt++) {
+  for (int rt = 0; rt < NRT; rt++) {
     const int rbase = p.n_off + nblk * 64 + rt * 32;
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const long long sf_off = p.save_f ? p.save_f - p.y : 0, ss_off = p.save_s ? p.save_s - p.y : 0;
   int round = 0;
 #pragma unroll
-  for (int rt = 0; rt < 2; rt++)
+  for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
     for (int pl = 0; pl < 3; pl++, round++) {
       float* X = lds + (round & 1) * WXB;
@@ -449,19 +450,22 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
 
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   p.ntz = ceil_div(p.Z, WPL), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
-  p.nblk = ceil_div(p.N, 64);
   p.nchunks = ceil_div(p.K, WKC);
   {
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.save_f) | reinterpret_cast<uintptr_t>(p.save_s);
     for (int i = 0; i < p.out.n; i++) bits |= reinterpret_cast<uintptr_t>(p.out.ptr[i]);
     p.pair_aligned = (bits & 7) == 0;
   }
-  const long long nwg = (long long)p.ntz * p.nty * p.ntx * p.nblk;
-  SR3D_CHECK(nwg < (1ll << 31) && B <= 65535, SR3D_E_ARG, "winograd conv: grid too large");
+  // 64-row blocks run with two 32-row tiles per workgroup; a last block of <= 32 rows runs with one (half the MFMAs)
+  const int nfull = p.N / 64, rem = p.N - nfull * 64;
+  const int n2 = nfull + (rem > 32 ? 1 : 0), n1 = (rem > 0 && rem <= 32) ? 1 : 0;
+  const long long nsp = (long long)p.ntz * p.nty * p.ntx;
+  SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31) && B <= 65535, SR3D_E_ARG, "winograd conv: grid too large");
   SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "winograd conv: more than 2^29 voxels per channel");
   static thread_local bool configured = false;
   if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
     configured = true;
   }
   void* tok = nullptr;
@@ -469,7 +473,15 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
     const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
     sr3d_prof_begin(SR3D_PROF_IGEMM_S1, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
   }
-  hipLaunchKernelGGL(wino_kernel, dim3((unsigned)nwg, B), dim3(WNT), kWinoLds, st, p);
+  p.nimg = n2 + n1;
+  if (n2 > 0) {
+    p.nblk = n2, p.nb_off = 0;
+    hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(WNT), kWinoLds, st, p);
+  }
+  if (n1 > 0) {
+    p.nblk = 1, p.nb_off = n2;
+    hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)nsp, B), dim3(WNT), kWinoLds, st, p);
+  }
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
