@@ -74,9 +74,14 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
                    const int* cbeg, float* image, hipStream_t st);
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st);
 // Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
-size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total);
-int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, float* dw, float* ws,
-                    hipStream_t st);
+// (the first `c_used` input channels; dW rows keep their full length d->Cin * 27)
+size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);
+int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw,
+                    float* ws, hipStream_t st);
+// VALU weight gradient for a few channels on one side (sr3d_wgrad_few.hip)
+size_t sr3d_wgrad_few_ws_bytes(const sr3d_conv_desc_t* d, int M, int few_n);
+int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const ChanCat& few, int few_c0, int few_n,
+                   int mode, float* dw, long long ldw, float* ws, hipStream_t st);
 
 // per-kernel HIP-event timing (off unless sr3d_profile_enable(1)); ids are SR3D_PROF_*
 bool sr3d_prof_active();

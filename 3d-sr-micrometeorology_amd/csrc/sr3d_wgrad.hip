@@ -508,6 +508,19 @@ inline bool wino_wgrad_on() {
 inline bool use_wino_wgrad(const sr3d_conv_desc_t* d, int n_total) {
   return wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0;
 }
+// 1..4 input channels beyond a multiple of 32 (a mask concatenated to the features) would cost a whole 32-channel
+// block: they go to the few-channel VALU kernel (sr3d_wgrad_few.hip) instead
+inline int wino_wgrad_c_used(const sr3d_conv_desc_t* d) {
+  const int rem = d->Cin % 32;
+  return (d->Cin >= 32 && rem >= 1 && rem <= 4) ? d->Cin - rem : d->Cin;
+}
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+inline size_t wino_wgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
+  const int cu = wino_wgrad_c_used(d);
+  size_t bytes = align256(sr3d_wino_wgrad_ws_bytes(d, n_total, cu));
+  if (cu < d->Cin) bytes += sr3d_wgrad_few_ws_bytes(d, n_total, d->Cin - cu);
+  return bytes;
+}
 inline bool wino_wgrad_slices_ok(const sr3d_slice_t* dy_srcs, int n_dy) {
   for (int i = 0; i < n_dy; i++)
     if (dy_srcs[i].channels % 4 || ((uintptr_t)dy_srcs[i].ptr & 7)) return false;
@@ -646,7 +659,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
   if (use_smalln(d, n_total, 1)) return (size_t)smalln_plan(d).S * d->Cin * 108 * 4;
   const Plan pl = make_plan(d, n_total);
   size_t bytes = (size_t)pl.S * pl.Npad * pl.Jpad * 4;
-  if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, sr3d_wino_wgrad_ws_bytes(d, n_total));
+  if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, wino_wgrad_total_ws(d, n_total));
   return bytes;
 }
 
@@ -686,14 +699,21 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     return SR3D_OK;
   }
   if (use_wino_wgrad(d, n_total) && wino_wgrad_slices_ok(dy_srcs, n_dy)) {
-    SR3D_CHECK(workspace_bytes >= sr3d_wino_wgrad_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
+    SR3D_CHECK(workspace_bytes >= wino_wgrad_total_ws(d, n_total), SR3D_E_WORKSPACE,
                "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
     ChanCat xc, dc;
     if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
     if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
     for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
     for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
-    return sr3d_wino_wgrad(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream);
+    const int cu = wino_wgrad_c_used(d);
+    if (int rc = sr3d_wino_wgrad(d, xc, dc, n_total, cu, (float*)dw, (float*)workspace, (hipStream_t)stream)) return rc;
+    if (cu < d->Cin) {
+      float* ws2 = (float*)((char*)workspace + align256(sr3d_wino_wgrad_ws_bytes(d, n_total, cu)));
+      return sr3d_wgrad_few(d, dc, n_total, xc, cu, d->Cin - cu, 0, (float*)dw, (long long)d->Cin * 27, ws2,
+                            (hipStream_t)stream);
+    }
+    return SR3D_OK;
   }
   const Plan pl = make_plan(d, n_total);
   SR3D_CHECK(workspace_bytes >= (size_t)pl.S * pl.Npad * pl.Jpad * 4, SR3D_E_WORKSPACE,

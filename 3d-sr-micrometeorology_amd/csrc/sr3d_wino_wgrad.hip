@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_sum_kernel(float* __restrict__
 
 // dW[n][c][kz][ky][kx] = sum_{xi} G[xi_y][ky] G[xi_x][kx] * (sum_s slab[s][kz*16 + xi][n][c])
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                               int S, int N, int Cin, int Npad, int Cpad) {
+                                                               int S, int N, int Cin, int ldc, int Npad, int Cpad) {
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
   const long long plane = (long long)Npad * Cpad;
   const long long total = (long long)N * Cin * 3;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
       for (int k = 0; k < S; k++) s += src[(long long)k * 48 * plane];
       u[xi] = s;
     }
-    float* out = dw + ((long long)n * Cin + c) * 27 + kz * 9;
+    float* out = dw + ((long long)n * ldc + c) * 27 + kz * 9;
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -399,9 +399,9 @@ struct GPlan {
   long long ntiles, per_split;
 };
 
-GPlan gplan(const sr3d_conv_desc_t* d, int n_total) {
+GPlan gplan(const sr3d_conv_desc_t* d, int n_total, int c_used) {
   GPlan g;
-  g.nblk = ceil_div(n_total, GNB), g.cblk = ceil_div(d->Cin, 32);
+  g.nblk = ceil_div(n_total, GNB), g.cblk = ceil_div(c_used, 32);
   g.Npad = g.nblk * GNB, g.Cpad = g.cblk * 32;
   g.nty = ceil_div(d->Y, 2), g.ntx = ceil_div(d->X, 2 * GT);
   g.ntiles = (long long)d->B * g.nty * g.ntx * d->Z;
@@ -424,16 +424,16 @@ GPlan gplan(const sr3d_conv_desc_t* d, int n_total) {
 
 }  // namespace
 
-size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total) {
-  const GPlan g = gplan(d, n_total);
+size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used) {
+  const GPlan g = gplan(d, n_total, c_used);
   return (size_t)g.S * 48 * g.Npad * g.Cpad * 4;
 }
 
-int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, float* dw, float* ws,
-                    hipStream_t st) {
-  const GPlan g = gplan(d, n_total);
+int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw,
+                    float* ws, hipStream_t st) {
+  const GPlan g = gplan(d, n_total, c_used);
   WinoWgradParams p{};
-  p.x = x, p.dy = dy, p.Cin = d->Cin, p.N = n_total;
+  p.x = x, p.dy = dy, p.Cin = c_used, p.N = n_total;
   p.Z = d->Z, p.Y = d->Y, p.X = d->X;
   p.nty = g.nty, p.ntx = g.ntx, p.ntiles = g.ntiles, p.per_split = g.per_split;
   p.slab = ws, p.Npad = g.Npad, p.Cpad = g.Cpad;
@@ -445,11 +445,11 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   }
   void* tok = nullptr;
   if (sr3d_prof_active())
-    sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st, &tok);
+    sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st, &tok);
   hipLaunchKernelGGL(wino_wgrad_kernel, dim3(g.S * g.cblk * g.nblk), dim3(512), kGLds, st, p);
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
-  const long long total = (long long)n_total * d->Cin * 3;
+  const long long total = (long long)n_total * c_used * 3;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (g.S > 1) {
     const long long count = (long long)48 * g.Npad * g.Cpad;
@@ -458,7 +458,7 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
     SR3D_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, 1, n_total,
-                     d->Cin, g.Npad, g.Cpad);
+                     c_used, d->Cin, g.Npad, g.Cpad);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
