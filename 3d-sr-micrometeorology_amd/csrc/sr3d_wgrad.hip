@@ -364,6 +364,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
 // contiguous range of 4x8x32-voxel tiles; a thread owns one (y, x) column of 4 voxels and keeps all
 // 27 taps x 4 rows = 108 partial sums in registers (sliding 3-plane window through the LDS halo tile);
 // at the end the 256 threads are reduced (wave shuffles, then LDS) and written to slab[split][c][n][tap].
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 struct SmallNParams {
   ChanCat x;
   const float* dy;     // (B, N, OZ, OY, OX), N <= 4
@@ -388,11 +390,11 @@ __global__ __launch_bounds__(256) void wgrad_smalln_kernel(const SmallNParams p)
   const long long xbs = cat_bstride(p.x, si);
   const bool vec = (p.X % 4 == 0) && ((reinterpret_cast<uintptr_t>(cat_ptr(p.x, si)) & 15) == 0);
 
-  float acc[4][27];
+  f32x2v acc[2][27];   // rows (0,1) and (2,3) as pairs: one v_pk_fma_f32 per pair and tap
 #pragma unroll
-  for (int n = 0; n < 4; n++)
+  for (int n = 0; n < 2; n++)
 #pragma unroll
-    for (int t = 0; t < 27; t++) acc[n][t] = 0.f;
+    for (int t = 0; t < 27; t++) acc[n][t] = f32x2v{0.f, 0.f};
 
   const long long t_begin = (long long)split * p.per_split;
   long long t_end = t_begin + p.per_split;
@@ -448,8 +450,9 @@ __global__ __launch_bounds__(256) void wgrad_smalln_kernel(const SmallNParams p)
 #pragma unroll
           for (int kx = 0; kx < 3; kx++) {
             const float xv = hp[(z + kz) * PZ + ky * RW + kx];
-#pragma unroll
-            for (int n = 0; n < 4; n++) acc[n][(kz * 3 + ky) * 3 + kx] += d[n] * xv;
+            const f32x2v xx = {xv, xv};
+            acc[0][(kz * 3 + ky) * 3 + kx] += f32x2v{d[0], d[1]} * xx;
+            acc[1][(kz * 3 + ky) * 3 + kx] += f32x2v{d[2], d[3]} * xx;
           }
     }
   }
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void wgrad_smalln_kernel(const SmallNParams p)
   for (int n = 0; n < 4; n++)
 #pragma unroll
     for (int t = 0; t < 27; t++) {
-      float v = acc[n][t];
+      float v = acc[n >> 1][t][n & 1];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if (lane == 0) red[wave * 108 + n * 27 + t] = v;

@@ -226,9 +226,11 @@ def main():
                          "kernel": "stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
                                    "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)",
                          "note": "achieved = ALGORITHMIC FLOPs of the 3x3x3 convolution (2*27*Cin*Cout per output voxel) / "
-                                 "kernel time; the Winograd kernel issues 2.25x fewer MFMA FLOPs than that "
-                                 "(executed_tflops), all in fp32",
+                                 "kernel time, so frac can exceed 1: the Winograd kernel issues 2.25x fewer MFMA FLOPs "
+                                 "than the algorithm counts.  executed_tflops / frac_executed price the MFMAs the "
+                                 "kernel really issues against the same fp32 MFMA peak (all arithmetic is fp32)",
                          "executed_tflops": ach / (2.25 if wino else 1.0),
+                         "frac_executed": ach / (2.25 if wino else 1.0) / FP32_MFMA_PEAK_TFLOPS,
                          "launches_per_step": dom["launches"] / args.steps,
                          "kernel_ms_per_step": dom["ms"] / args.steps},
             "step_tflops": FLOP_PER_VOXEL * value / 1e12,

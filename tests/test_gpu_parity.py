@@ -202,7 +202,9 @@ def test_fullwidth_layers(eng):
     # activation: a pre-activation within rounding distance of 0 may legitimately change sign between two fp32
     # algorithms, and a single flipped LeakyReLU slope is a 1e-3 change of the gradients at these sizes.
     ((7, 10, 36), 1, 40, 72, None), ((3, 5, 18), 1, 17, 8, None), ((9, 6, 50), 1, 33, 12, None),
-    ((21, 4, 16), 1, 64, 64, None)])
+    ((21, 4, 16), 1, 64, 64, None),
+    # 32 k + 1..3 input channels: the odd channels take the few-channel weight-gradient kernel; odd K chunk
+    ((5, 6, 16), 1, 33, 12, None), ((4, 8, 32), 1, 66, 40, None), ((3, 5, 18), 1, 35, 8, None)])
 def test_odd_shapes_vs_oracle(eng, shape, stride, cin, cout, act):
     """ragged / odd / tiny grids: tile-edge masking, stride-2 parity classes with odd extents"""
     import torch.nn.functional as F
