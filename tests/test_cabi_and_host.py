@@ -49,8 +49,9 @@ def test_argument_errors_are_reported_not_crashes(eng):
     with pytest.raises(RuntimeError, match="failed"):
         L.check(rc, "sr3d_adam_step")
     # workspace queries are pure host arithmetic
-    # stride 1 -> Winograd image [row block][chunk][kz 3][xi 16][4 ch][32 rows]; stride 2 -> direct [..][27 taps][4][32]
-    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 1 * 3 * 16 * 4 * 32 * 4
+    # stride 1 -> Winograd image [64-row block][chunk of 2 ch][kz 3][xi 16][row tile 2][2 ch][32 rows];
+    # stride 2 -> direct [..][27 taps][4][32]
+    assert lib.sr3d_packed_weight_bytes(C.byref(d), L.PACK_FWD) == 1 * 2 * 3 * 16 * 2 * 2 * 32 * 4
     d2 = L.conv_desc(1, 4, 8, 8, 8, 8, 2)
     assert lib.sr3d_packed_weight_bytes(C.byref(d2), L.PACK_FWD) == 1 * 1 * 27 * 4 * 32 * 4
     d4 = L.conv_desc(1, 69, 4, 8, 8, 8, 1)   # <= 4 output channels: the VALU path's [Cin][27][4] image
