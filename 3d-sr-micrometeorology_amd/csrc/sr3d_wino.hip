@@ -374,9 +374,11 @@ struct WinoPackParams {
   int cbeg[SR3D_MAX_SRC];
 };
 
-__global__ void wino_pack_kernel(const WinoPackParams p) {
+// One thread per (row, channel, kz): it reads the 9 filter values of that plane once and writes all 16 transform
+// points (the first version had one thread per image element, i.e. 16 threads re-reading the same 9 values).
+__global__ __launch_bounds__(256) void wino_pack_kernel(const WinoPackParams p) {
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  const long long total = (long long)p.nblk * p.nchunks * WUS;
+  const long long total = (long long)p.nblk * p.nchunks * (WUS / 16);
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     long long r = e;
@@ -386,14 +388,14 @@ __global__ void wino_pack_kernel(const WinoPackParams p) {
     r /= WKC;
     const int rt = r % 2;
     r /= 2;
-    const int xi = r % 16;
-    r /= 16;
     const int kz = r % 3;
     r /= 3;
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
     const int n = nb * 64 + rt * 32 + rr, k = chunk * WKC + kc;
-    float val = 0.f;
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) g[i / 3][i % 3] = 0.f;
     if (n < p.N && k < p.K) {
       const float* w = nullptr;  // -> w[co][ci][0][0][0]
       bool flip = false;
@@ -409,18 +411,25 @@ __global__ void wino_pack_kernel(const WinoPackParams p) {
         flip = true;
       }
       if (w != nullptr) {
-        const int xy = xi >> 2, xx = xi & 3;
         const int kzz = flip ? 2 - kz : kz;
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-          for (int kx = 0; kx < 3; kx++) {
-            const int kyy = flip ? 2 - ky : ky, kxx = flip ? 2 - kx : kx;
-            val += G[xy][ky] * G[xx][kx] * w[(kzz * 3 + kyy) * 3 + kxx];
-          }
+          for (int kx = 0; kx < 3; kx++) g[ky][kx] = w[(kzz * 3 + (flip ? 2 - ky : ky)) * 3 + (flip ? 2 - kx : kx)];
       }
     }
-    p.up[e] = val;
+    // U = G g G^T
+    float t[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) t[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+    float* dst = p.up + ((((((long long)nb * p.nchunks + chunk) * 3 + kz) * 16) * 2 + rt) * WKC + kc) * 32 + rr;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; b2++)
+        dst[(long long)(a * 4 + b2) * (2 * WKC * 32)] = t[a][0] * G[b2][0] + t[a][1] * G[b2][1] + t[a][2] * G[b2][2];
   }
 }
 
@@ -441,7 +450,7 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
   p.nchunks = ceil_div(K, WKC), p.nblk = ceil_div(rows, 64);
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
   for (int i = 0; i < SR3D_MAX_SRC; i++) p.cbeg[i] = cbeg ? cbeg[i] : 0;
-  const long long total = (long long)p.nblk * p.nchunks * WUS;
+  const long long total = (long long)p.nblk * p.nchunks * (WUS / 16);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
   SR3D_HIP(hipGetLastError());
