@@ -81,7 +81,7 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
 // VALU weight gradient for a few channels on one side (sr3d_wgrad_few.hip)
 size_t sr3d_wgrad_few_ws_bytes(const sr3d_conv_desc_t* d, int M, int few_n);
 int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const ChanCat& few, int few_c0, int few_n,
-                   int mode, float* dw, long long ldw, float* ws, hipStream_t st);
+                   float* dw, long long ldw, float* ws, hipStream_t st);
 
 // per-kernel HIP-event timing (off unless sr3d_profile_enable(1)); ids are SR3D_PROF_*
 bool sr3d_prof_active();

@@ -34,7 +34,6 @@ struct WgradParams {
   long long per_split; // tiles per workgroup
   float* slab;         // [S][Npad][Jpad]
   int Npad, Jpad;
-  int dbg;             // timing experiments only (SR3D_WGRAD_DBG): 1 no global loads, 2 no LDS stores, 8 no MFMA
 };
 
 // One 512-thread workgroup per CU: WAVES_N waves split the rows (32 each), 8 / WAVES_N waves split the
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
       const int cl = wave + 8 * k;     // wave-uniform
       const int gc = c_lo + cl;
       gfloat_p base = nullptr;
-      if (cl < NCH && gc < p.Cin && zok && !(p.dbg & 1)) {
+      if (cl < NCH && gc < p.Cin && zok) {
         const int si = cat_find(p.x, gc);
         base = (gfloat_p)cat_ptr(p.x, si) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
       }
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
       const int oy = c_oy0 + vv / 32, ox = c_ox0 + (vv & 31);
       const gfloat_p base = (gfloat_p)dptr[n];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (base != nullptr && oy < p.OY && !(p.dbg & 1)) {
+      if (base != nullptr && oy < p.OY) {
         const gfloat_p row = base + (long long)c_b * dbs[n] + ((long long)c_oz * p.OY + oy) * p.OX;
         if (VEC) {
           if (ox + 3 < p.OX) v = *(const __attribute__((address_space(1))) f32x4*)(row + ox);
@@ -273,13 +272,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
         for (int q = 0; q < NEWP; q++)
           if (k0 + q < 3) store_plane(vx[q], k0 + q);
       }
-    } else if (!(p.dbg & 2)) {
+    } else {
       // steady state: the NEWP new planes (prefetched during the previous tile) replace the oldest ones
       s0 = (s0 + NEWP) % 3;
 #pragma unroll
       for (int q = 0; q < NEWP; q++) store_plane(vx[q], (s0 + 3 - NEWP + q) % 3);
     }
-    if (!(p.dbg & 2) || tile == t_begin) {
+    {
 #pragma unroll
       for (int i = 0; i < PER; i++) {
         const int e = (tid + i * NT) * 4;
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int t = 0; t < CTW; t++) bv[t] = Xs[boff[t] + (row * S_IN) * RW + xx * S_IN];
     };
-    if (!(p.dbg & 8)) {
+    {
       float a0, a1, b0[CTW], b1[CTW];
       frag(0, a0, b0);
 #pragma unroll
@@ -336,11 +335,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
           }
         }
       }
-    } else if (more) {
-#pragma unroll
-      for (int q = 0; q < NEWP; q++)
-        if (!fresh) load_plane(vx[q], c_oz * S_IN - 1 + (3 - NEWP) + q);
-      load_dy();
     }
   }
 
@@ -713,7 +707,7 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     if (int rc = sr3d_wino_wgrad(d, xc, dc, n_total, cu, (float*)dw, (float*)workspace, (hipStream_t)stream)) return rc;
     if (cu < d->Cin) {
       float* ws2 = (float*)((char*)workspace + align256(sr3d_wino_wgrad_ws_bytes(d, n_total, cu)));
-      return sr3d_wgrad_few(d, dc, n_total, xc, cu, d->Cin - cu, 0, (float*)dw, (long long)d->Cin * 27, ws2,
+      return sr3d_wgrad_few(d, dc, n_total, xc, cu, d->Cin - cu, (float*)dw, (long long)d->Cin * 27, ws2,
                             (hipStream_t)stream);
     }
     return SR3D_OK;
@@ -732,10 +726,6 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   p.OZ = OZ, p.OY = OY, p.OX = OX;
   p.nty = pl.nty, p.ntx = pl.ntx, p.ntiles = pl.ntiles, p.per_split = pl.per_split;
   p.slab = (float*)workspace, p.Npad = pl.Npad, p.Jpad = pl.Jpad;
-  {
-    static const int dbg = getenv("SR3D_WGRAD_DBG") ? atoi(getenv("SR3D_WGRAD_DBG")) : 0;
-    p.dbg = dbg;
-  }
   dim3 grid(pl.S, pl.jblk, pl.nblk);
   SR3D_CHECK(pl.jblk <= 65535 && pl.nblk <= 65535, SR3D_E_ARG, "conv3d_bwd_weight: too many blocks");
   hipStream_t st = (hipStream_t)stream;

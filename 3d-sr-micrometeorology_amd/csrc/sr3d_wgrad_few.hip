@@ -10,7 +10,6 @@
 // the x window of the few channels sits in LDS (zero padded halo tile) and is read as BROADCASTS (all lanes read
 // the same address: one LDS cycle), 2 LDS reads per 12 FMAs.  No MFMA: with 1-2 columns the matrix pipe would
 // run at 3-6 % utilisation, the vector ALUs finish sooner.
-// mode 1 swaps the roles (many x channels, few dy rows; taps mirrored): dW[n][c][tap] = sum_u x[c][u] dy[n][u - tap + 1].
 #include <algorithm>
 
 #include "sr3d_common.h"
@@ -162,10 +161,10 @@ __global__ __launch_bounds__(256, F == 2 ? 2 : 1) void wgrad_few_kernel(const Fe
   }
 }
 
-// mode 0: dw[m * ldw + (c0 + f) * 27 + t];   mode 1: dw[(n0 + f) * ldw + m * 27 + (26 - t)]
+// dw[m * ldw + (c0 + f) * 27 + t] = sum over the splits (fixed order)
 __global__ __launch_bounds__(256) void wgrad_few_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                               int S, int M, int Mpad, int F, int few_n, int few_c0,
-                                                              int mode, long long ldw) {
+                                                              long long ldw) {
   const int total = M * F * 27;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
@@ -174,10 +173,7 @@ __global__ __launch_bounds__(256) void wgrad_few_reduce_kernel(const float* __re
   const float* src = slab + (long long)mm * (F * 27) + ft;
   float s = 0.f;
   for (int k = 0; k < S; k++) s += src[(long long)k * Mpad * (F * 27)];
-  if (mode == 0)
-    dw[(long long)mm * ldw + (few_c0 + f) * 27 + t] = s;
-  else
-    dw[(long long)(few_c0 + f) * ldw + mm * 27 + (26 - t)] = s;
+  dw[(long long)mm * ldw + (few_c0 + f) * 27 + t] = s;
 }
 
 struct FewPlan {
@@ -219,7 +215,7 @@ size_t sr3d_wgrad_few_ws_bytes(const sr3d_conv_desc_t* d, int M, int few_n) {
 }
 
 int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const ChanCat& few, int few_c0, int few_n,
-                   int mode, float* dw, long long ldw, float* ws, hipStream_t st) {
+                   float* dw, long long ldw, float* ws, hipStream_t st) {
   SR3D_CHECK(few_n >= 1 && few_n <= 4, SR3D_E_ARG, "wgrad_few: 1..4 channels on the small side (got %d)", few_n);
   SR3D_CHECK(d->stride == 1, SR3D_E_ARG, "wgrad_few: stride 1 only");
   const FewPlan pl = few_plan(d, M, few_n);
@@ -236,7 +232,7 @@ int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const 
   if (rc) return rc;
   const int total = M * pl.F * 27;
   hipLaunchKernelGGL(wgrad_few_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float*)ws, dw, pl.S, M,
-                     pl.Mpad, pl.F, few_n, few_c0, mode, ldw);
+                     pl.Mpad, pl.F, few_n, few_c0, ldw);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
