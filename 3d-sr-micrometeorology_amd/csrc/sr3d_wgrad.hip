@@ -503,7 +503,9 @@ inline bool wino_wgrad_on() {
   return on && sr3d_wino_enabled();
 }
 inline bool use_wino_wgrad(const sr3d_conv_desc_t* d, int n_total) {
-  return wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0;
+  // (the kernel's buffer descriptors span 4 dY rows of one sample: 16 * Z*Y*X bytes must fit 31 bits)
+  return wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0 &&
+         (long long)d->Z * d->Y * d->X < (1ll << 27);
 }
 // 1..4 input channels beyond a multiple of 32 (a mask concatenated to the features) would cost a whole 32-channel
 // block: they go to the few-channel VALU kernel (sr3d_wgrad_few.hip) instead
