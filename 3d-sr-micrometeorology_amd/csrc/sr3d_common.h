@@ -54,6 +54,7 @@ struct SrWinoParams {
   int Z, Y, X;         // grid (stride 1: input grid = output grid)
   int ntz, nty, ntx, nblk, nchunks;   // set by sr3d_wino_launch
   int nb_off, nimg;    // first 64-row block of this launch; blocks in the packed image
+  int rt_split;        // one-tile launch with one workgroup per 32-row tile
   const float* up;     // transformed + packed weights
   int N;               // GEMM rows (gated: 32 per 16 channels)
   int n_off;

@@ -76,7 +76,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nblk = p.nb_off + v % p.nblk;   // 64-row block of the layer (index into the packed image)
+  // 64-row block of the layer (index into the packed image) and, for the one-tile variant on small grids, which
+  // of its two 32-row tiles this workgroup takes (rt_split: the launch has two workgroups per 64-row block)
+  const int rblk = v % p.nblk;
+  const int nblk = p.nb_off + (NRT == 1 && p.rt_split ? rblk >> 1 : rblk);
+  const int rt0 = (NRT == 1 && p.rt_split) ? (rblk & 1) : 0;
   int blk = v / p.nblk;
   const int tix = blk % p.ntx;
   blk /= p.ntx;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  const int fu = 2 * wave * (2 * WKC * 32) + lane;   // xi = 2 * wave: A fragments  [kz][xi][rt][c][32]
+  const int fu = 2 * wave * (2 * WKC * 32) + rt0 * (WKC * 32) + lane;   // xi = 2 * wave: A fragments  [kz][xi][rt][c][32]
   const int fv = 2 * wave * (WKC * 32) + lane;       //                 B fragments  [plane][xi][c][32]
   float a[3][2][NRT], bq[3][3][2];                     // fragment sets (one per kz): [set][xl][rt], [set][plane][xl]
   auto frags = [&](const float* U, const float* V, const int kz, const int set) {
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const int ystride = unsh ? 2 * p.TX_ : p.TX_, xstride = unsh ? 2 : 1;
 #pragma unroll
   for (int rt = 0; rt < NRT; rt++) {
-    const int rbase = p.n_off + nblk * 64 + rt * 32;
+    const int rbase = p.n_off + nblk * 64 + (rt0 + rt) * 32;
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
       const int n = rbase + er + 16 * hh;
@@ -483,13 +487,22 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
     sr3d_prof_begin(SR3D_PROF_IGEMM_S1, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
   }
   p.nimg = n2 + n1;
-  if (n2 > 0) {
-    p.nblk = n2, p.nb_off = 0;
-    hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(WNT), kWinoLds, st, p);
-  }
-  if (n1 > 0) {
-    p.nblk = 1, p.nb_off = n2;
-    hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)nsp, B), dim3(WNT), kWinoLds, st, p);
+  // Small grids (levels 3-4 of the U-Net) give fewer 64-row workgroups than the chip has CUs: run every 32-row tile
+  // as its own workgroup instead (same image, twice the workgroups, each with half the MFMAs).
+  const int ntile32 = ceil_div(p.N, 32);
+  if (nsp * (n2 + n1) < 160 && ntile32 > n2 + n1) {
+    p.nblk = ntile32, p.nb_off = 0, p.rt_split = 1;
+    hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)(nsp * ntile32), B), dim3(WNT), kWinoLds, st, p);
+  } else {
+    p.rt_split = 0;
+    if (n2 > 0) {
+      p.nblk = n2, p.nb_off = 0;
+      hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(WNT), kWinoLds, st, p);
+    }
+    if (n1 > 0) {
+      p.nblk = 1, p.nb_off = n2;
+      hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)nsp, B), dim3(WNT), kWinoLds, st, p);
+    }
   }
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
