@@ -407,7 +407,11 @@ inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
 }
 
 // stride-1 convolutions (forward and input gradient) run on the Winograd kernel (sr3d_wino.hip)
-inline bool use_wino(const sr3d_conv_desc_t* d) { return d->stride == 1 && sr3d_wino_enabled(); }
+// (the Winograd kernel keeps a table of channel pointers in LDS: at most 4096 channels on the K side, which is Cin
+// forward and n_dy * Cout for the input gradient - checked again there)
+inline bool use_wino(const sr3d_conv_desc_t* d) {
+  return d->stride == 1 && sr3d_wino_enabled() && d->Cin <= 4096 && d->Cout <= 4096;
+}
 inline int wino_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 32 * ((d->Cout + 15) / 16) : d->Cout;
 }
@@ -829,7 +833,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   pk.K = K, pk.N = rows, pk.nchunks = p.nchunks;
   float* image = (float*)workspace;
 
-  if (use_wino(d)) {
+  if (use_wino(d) && K <= 4096) {
     SrWinoParams q{};
     q.in = p.in, q.out = p.out;
     q.K = K, q.N = rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;

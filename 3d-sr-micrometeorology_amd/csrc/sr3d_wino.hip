@@ -46,7 +46,8 @@ constexpr int WUS = 3 * 16 * 2 * WKC * 32;  // U buffer [kz][xi][row tile][c][32
 constexpr int WNT = 512;
 constexpr int WXB = 8 * 2 * 1024;           // epilogue exchange buffer [wave][value][32 rows x 32 tiles]
 constexpr int kWinoLdsFloats = (2 * WVB + 2 * WUS + 3 * WRB) > 2 * WXB ? (2 * WVB + 2 * WUS + 3 * WRB) : 2 * WXB;
-constexpr size_t kWinoLds = (size_t)kWinoLdsFloats * 4;
+constexpr int WCT = 4096;                   // channel-pointer table entries (8 bytes each) behind the buffers
+constexpr size_t kWinoLds = (size_t)kWinoLdsFloats * 4 + (size_t)WCT * 8;
 static_assert(kWinoLds <= 160 * 1024, "LDS budget");
 
 typedef const __attribute__((address_space(1))) float* gfloat_p;
@@ -103,14 +104,24 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
     const bool ok = e < WRE && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
     roff[i] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
   }
+  // Base pointer of every input channel (virtual concat, this sample), worked out once into an LDS table: the
+  // per-chunk descriptor is then one broadcast LDS read + two readfirstlanes instead of ~60 scalar instructions
+  // of slice lookup and 64-bit multiplies, which sat in every wave's instruction stream next to the MFMAs.
+  unsigned long long* ctab = reinterpret_cast<unsigned long long*>(lds + kWinoLdsFloats);
+  for (int c = tid; c < p.K; c += WNT) {
+    const int si = cat_find(p.in, c);
+    ctab[c] = reinterpret_cast<unsigned long long>(cat_ptr(p.in, si) + ((long long)b * cat_bstride(p.in, si) +
+                                                                        (long long)(c - cat_cbeg(p.in, si)) * ZYX));
+  }
+  __syncthreads();
   auto dma_raw = [&](const int chunk, float* R) {
 #pragma unroll
     for (int c = 0; c < WKC; c++) {
       const int gc = chunk * WKC + c;   // wave-uniform
       const int gcc = gc < p.K ? gc : p.K - 1;   // branch-free: channels past the end get an empty descriptor
-      const int si = cat_find(p.in, gcc);
-      const gfloat_p base =
-          (gfloat_p)cat_ptr(p.in, si) + ((long long)b * cat_bstride(p.in, si) + (long long)(gcc - cat_cbeg(p.in, si)) * ZYX);
+      const unsigned long long a = ctab[gcc];
+      const unsigned long long base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)a);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -475,6 +486,7 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31) && B <= 65535, SR3D_E_ARG, "winograd conv: grid too large");
   SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "winograd conv: more than 2^29 voxels per channel");
+  SR3D_CHECK(p.K <= WCT, SR3D_E_ARG, "winograd conv: more than %d input channels", WCT);
   static thread_local bool configured = false;
   if (!configured) {
     SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));

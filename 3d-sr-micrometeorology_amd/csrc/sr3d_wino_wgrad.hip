@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   // registers, no ds_write): lane i of the wave instruction lands at row + 4 i bytes, which is the row layout.
   auto load_x = [&](float* buf) {
     const bool zok = n_valid && (unsigned)s_u < (unsigned)p.Z;
-    const long long zo = (long long)s_u * YX;
+    const unsigned zo = zok ? (unsigned)s_u * (unsigned)YX : 0u;   // 32-bit: Z*Y*X < 2^27 (host dispatch)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   gfloat_p lag_d[2] = {nullptr, nullptr};
   auto lag_state = [&]() { lag_u = s_u, lag_out = n_out, lag_doffc = doffc, lag_d[0] = dcur[0], lag_d[1] = dcur[1]; };
   auto load_dy = [&]() {
-    const long long zo = (long long)(lag_u - 1) * YX;
+    const unsigned zo = lag_out ? (unsigned)(lag_u - 1) * (unsigned)YX : 0u;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
