@@ -267,7 +267,27 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   // Global loads run two steps ahead for x (three raw LDS buffers) and one full step ahead for dY.
   const int fl = lane;   // fragments are 64 consecutive floats
   int rb = 0;            // raw buffer of step s
+  // The last 12 MFMAs of a step are issued AFTER its barrier, at the top of the next iteration: they only read
+  // registers, and the matrix pipe works through them while the wave does the scalar bookkeeping and issues the
+  // loads of the next step (which would otherwise run with an idle pipe).  Zero fragments for the first iteration.
+  float a[2][2][2], bq[2][2][3];
+#pragma unroll
+  for (int xl = 0; xl < 2; xl++) {
+    a[1][xl][0] = a[1][xl][1] = 0.f;
+    bq[1][xl][0] = bq[1][xl][1] = bq[1][xl][2] = 0.f;
+  }
+  auto mfmas = [&](const int set) {
+#pragma unroll
+    for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+      for (int xl = 0; xl < 2; xl++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          acc[(kz * 2 + xl) * 2 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              a[set][xl][nt], bq[set][xl][kz], acc[(kz * 2 + xl) * 2 + nt], 0, 0, 0);
+  };
   for (int s = 0; cur_valid || prev_out; s++) {
+    mfmas(1);                     // fourth k-step of the previous iteration
     const int rb2 = rb >= 1 ? rb - 1 : 2;   // (rb + 2) % 3
     lag_state();                  // step s+1
     next_step();                  // -> step s+2 (scalar; per-lane offsets only when a new column starts)
@@ -276,7 +296,6 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     const float* v1p = Vs + ((s + 2) & 3) * GVS + fl;
     const float* v2p = Vs + ((s + 3) & 3) * GVS + fl;
     const float* mp = Ms + ((s + 1) & 1) * GMB + fl;
-    float a[2][2][2], bq[2][2][3];
     auto frags = [&](const int ks, const int set) {
 #pragma unroll
       for (int xl = 0; xl < 2; xl++) {
@@ -286,16 +305,6 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
         const int o = (xi * GT + 2 * ks) * 32;
         bq[set][xl][0] = v0p[o], bq[set][xl][1] = v1p[o], bq[set][xl][2] = v2p[o];
       }
-    };
-    auto mfmas = [&](const int set) {
-#pragma unroll
-      for (int kz = 0; kz < 3; kz++)
-#pragma unroll
-        for (int xl = 0; xl < 2; xl++)
-#pragma unroll
-          for (int nt = 0; nt < 2; nt++)
-            acc[(kz * 2 + xl) * 2 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                a[set][xl][nt], bq[set][xl][kz], acc[(kz * 2 + xl) * 2 + nt], 0, 0, 0);
     };
     frags(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -312,8 +321,6 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     frags(3, 1);
     mfmas(0);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(1);
-    __builtin_amdgcn_sched_barrier(0);
     // the rows of step s+1 (issued one step ago) have landed; younger loads (12 per wave) may stay in flight
     // (a bare s_barrier: __syncthreads() carries a release fence that would drain the younger LDS-DMA loads too)
     asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     nx_valid = n_valid, nx_out = n_out;
     rb = rb == 2 ? 0 : rb + 1;
   }
+  mfmas(1);   // fourth k-step of the last iteration
 
   // ---- partial dU block -> slab[split][kz*16 + xi][n][c]
   const int c = cb * 32 + (lane & 31);
