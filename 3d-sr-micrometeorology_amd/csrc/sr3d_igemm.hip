@@ -288,7 +288,8 @@ struct SmallFwdParams {
   int ntz, nty, ntx;
   const float* w;      // [K][27][4]
   const float* bias;   // may be null
-  float* y;            // (B, N, Z, Y, X)
+  float* y;            // (B, N, Z, Y, X), or N channels inside a wider tensor (y_bstride)
+  long long y_bstride; // elements between samples of y
   int act;
 };
 
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
     for (int n = 0; n < 4; n++) {
       if (n >= p.N) break;
       const float bv = p.bias ? p.bias[n] : 0.f;
-      float* o = p.y + (((long long)b * p.N + n) * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
+      float* o = p.y + (long long)b * p.y_bstride + ((long long)n * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
       float r[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) r[i] = act_apply(acc[i][n] + bv, p.act);
@@ -400,6 +401,16 @@ __global__ void pack_smalln_kernel(const float* __restrict__ w, float* __restric
   if (e >= K * 108) return;
   const int n = e & 3, r = e >> 2;  // r = c*27 + t
   wp[e] = n < N ? w[(long long)n * K * 27 + r] : 0.f;
+}
+
+// input-gradient rows on the VALU path: wp[(k*27 + t)*4 + r] = W[k][ci0 + r][26 - t]  (k over feat then gate)
+__global__ void pack_smalln_bwd_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wp,
+                                       int Cout, int Cin, int K, int ci0, int nrows) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * 108) return;
+  const int r = e & 3, kt = e >> 2, k = kt / 27, tp = kt - k * 27;
+  const float* w = k < Cout ? w1 + (long long)k * Cin * 27 : w2 + (long long)(k - Cout) * Cin * 27;
+  wp[e] = r < nrows ? w[(ci0 + r) * 27 + (26 - tp)] : 0.f;
 }
 
 inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
@@ -696,6 +707,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     q.K = d->Cin, q.N = d->Cout, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
     q.ntz = ceil_div(d->Z, 4), q.nty = ceil_div(d->Y, 8), q.ntx = ceil_div(d->X, 32);
     q.w = (const float*)w_packed, q.bias = (const float*)bias, q.y = (float*)y, q.act = act;
+    q.y_bstride = (long long)d->Cout * d->Z * d->Y * d->X;
     SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_fwd: batch too large");
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3(q.ntz * q.nty * q.ntx, d->B), dim3(256), 0, (hipStream_t)stream, q);
     SR3D_HIP(hipGetLastError());
@@ -781,7 +793,8 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   if (check_desc(d) != SR3D_OK || (n_dy != 1 && n_dy != 2)) return 0;
   // upper bound: every input channel needs a gradient; stride 2 stores the 8 parity-class images (27 taps in total)
   const size_t direct = image_floats(ceil_div(d->Cin, 32), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
-  const size_t wino = use_wino(d) ? sr3d_wino_image_floats(d->Cin, n_dy * d->Cout) * 4 : 0;
+  // (+ the [K][27][4] image of up to 4 remainder rows that take the VALU kernel)
+  const size_t wino = use_wino(d) ? sr3d_wino_image_floats(d->Cin, n_dy * d->Cout) * 4 + (size_t)n_dy * d->Cout * 108 * 4 : 0;
   return direct > wino ? direct : wino;
 }
 
@@ -834,13 +847,37 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   float* image = (float*)workspace;
 
   if (use_wino(d) && K <= 4096) {
+    // 1..4 gradient rows beyond a multiple of 64 (e.g. 193 = 3 * 64 + 1) would cost a whole 32-row Winograd tile per
+    // voxel block: when they are the last channels of the last destination slice they take the small-N VALU kernel
+    int rem = rows % 64;
+    const sr3d_slice_t& last = need[nn - 1];
+    // (on the small grids of the deep levels the extra launches cost more than the padded tile)
+    if (!(rows > 64 && rem >= 1 && rem <= 4 && last.channels >= rem && (long long)d->Z * d->Y * d->X >= 500000)) rem = 0;
+    const int main_rows = rows - rem;
     SrWinoParams q{};
     q.in = p.in, q.out = p.out;
-    q.K = K, q.N = rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
     q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
     q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE, q.up = image;
-    if (int rc = sr3d_wino_pack(pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
-    return sr3d_wino_launch(q, d->B, st);
+    if (int rc = sr3d_wino_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
+    if (int rc = sr3d_wino_launch(q, d->B, st)) return rc;
+    if (rem > 0) {
+      float* wsm = image + sr3d_wino_image_floats(main_rows, K);
+      const int ci0 = pk.cbeg[nn - 1] + last.channels - rem;   // input channel of the first remainder row
+      hipLaunchKernelGGL(pack_smalln_bwd_kernel, dim3(ceil_div(K * 108, 256)), dim3(256), 0, st, pk.w1, pk.w2, wsm, d->Cout,
+                         d->Cin, K, ci0, rem);
+      SR3D_HIP(hipGetLastError());
+      SmallFwdParams sq{};
+      sq.in = p.in, sq.K = K, sq.N = rem, sq.Z = d->Z, sq.Y = d->Y, sq.X = d->X;
+      sq.ntz = ceil_div(d->Z, 4), sq.nty = ceil_div(d->Y, 8), sq.ntx = ceil_div(d->X, 32);
+      const long long vox = (long long)d->Z * d->Y * d->X;
+      sq.w = wsm, sq.bias = nullptr, sq.act = SR3D_ACT_NONE;
+      sq.y = (float*)last.ptr + (long long)(last.channels - rem) * vox, sq.y_bstride = (long long)last.channels * vox;
+      SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_bwd_data: batch too large");
+      hipLaunchKernelGGL(smalln_fwd_kernel, dim3(sq.ntz * sq.nty * sq.ntx, d->B), dim3(256), 0, st, sq);
+      SR3D_HIP(hipGetLastError());
+    }
+    return SR3D_OK;
   }
   if (d->stride == 1) {
     pk.ntaps = 27;
