@@ -46,6 +46,15 @@ struct IgemmParams {
   int Cg;              // gated: width of one branch (channels of y / save_f / save_s)
   int n_off;           // first GEMM row of this launch (a layer's rows may be covered by two launches)
   int grid_nblk;       // row blocks of this launch
+  // Stride-2 input gradient: the 8 output-parity classes run as ONE launch (blockIdx.z = class); each class has its
+  // own tap list, weight image, o-space grid and output parity.  ncls == 0: the fields above describe the launch.
+  int ncls;
+  struct Cls {
+    int ntaps;
+    int tap_off[8];
+    long long wp_off;    // floats from wp
+    int OZ, OY, OX, pz, py, px;
+  } cls[8];
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -93,6 +102,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // launch-wide or per-class (blockIdx.z) description
+  int ntaps = p.ntaps, OZ = p.OZ, OY = p.OY, OX = p.OX, pz = p.pz, py = p.py, px = p.px;
+  const int* tap_off = p.tap_off;
+  const float* wp = p.wp;
+  if (p.ncls > 0) {
+    const IgemmParams::Cls& c = p.cls[blockIdx.z];
+    ntaps = c.ntaps, OZ = c.OZ, OY = c.OY, OX = c.OX, pz = c.pz, py = c.py, px = c.px;
+    tap_off = c.tap_off, wp = wp + c.wp_off;
+  }
   const int nblk = v % p.grid_nblk;
   int tile = v / p.grid_nblk;
   const int tix = tile % p.ntx;
@@ -101,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   const int tiz = tile / p.nty;
   const int b = blockIdx.y;
   const int oz0 = tiz * TZ, oy0 = tiy * TY, ox0 = tix * 32;
+  if (p.ncls > 0 && (oz0 >= OZ || oy0 >= OY || ox0 >= OX)) return;   // the grid is sized for the largest class
   const int gz0 = oz0 * S_IN + LO, gy0 = oy0 * S_IN + LO, gx0 = ox0 * S_IN + LO;
   const long long IZYX = (long long)p.IZ * p.IY * p.IX;
 
@@ -135,14 +154,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                     (unsigned)gx < (unsigned)p.IX;
     hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
   }
-  const int wblock = p.ntaps * KC * BN;  // floats per (nblk, chunk)
+  const int wblock = ntaps * KC * BN;  // floats per (nblk, chunk)
   const int ninstr = (wblock + 255) / 256;  // 1 KiB LDS-DMA pieces (the last one may be partial: wblock % 128 == 0)
 
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
     __syncthreads();  // everyone is done reading the previous chunk
     // ---- weights: contiguous block, asynchronous global -> LDS (no VGPRs)
     {
-      const float* gw = p.wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
+      const float* gw = wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
       for (int i = wave; i < ninstr; i += 4)
         if (i * 256 + lane * 4 < wblock)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
@@ -172,9 +191,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
     __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA has landed)
 
-    for (int t = 0; t < p.ntaps; t++) {
+    for (int t = 0; t < ntaps; t++) {
       const float* wt = Ws + t * (KC * BN) + a_lane;
-      const float* ht = Hs + p.tap_off[t];
+      const float* ht = Hs + tap_off[t];
 #pragma unroll
       for (int kk = 0; kk < KC / 2; kk++) {
         float a[RT], bb[CT];
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       for (int j = 0; j < CT; j++) {
         const int ct = wm * CT + j;
         const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
-        if (oz >= p.OZ || oy >= p.OY || ox >= p.OX) continue;
+        if (oz >= OZ || oy >= OY || ox >= OX) continue;
         const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
 #pragma unroll
         for (int i = 0; i < RT; i += 2) {
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < CT; j++) {
       const int ct = wm * CT + j;
       const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
-      if (oz >= p.OZ || oy >= p.OY || ox >= p.OX) continue;
+      if (oz >= OZ || oy >= OY || ox >= OX) continue;
 #pragma unroll
       for (int i = 0; i < RT; i++)
 #pragma unroll
@@ -264,9 +283,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         for (int j = 0; j < CT; j++) {
           const int ct = wm * CT + j;
           const int oz = oz0 + ct / TY, oy = oy0 + ct % TY;
-          if (oz < p.OZ && oy < p.OY && ox < p.OX) {
-            const long long sp = ((long long)(oz * p.s_out + p.pz) * p.TY_ + (oy * p.s_out + p.py)) * p.TX_ +
-                                 (ox * p.s_out + p.px);
+          if (oz < OZ && oy < OY && ox < OX) {
+            const long long sp = ((long long)(oz * p.s_out + pz) * p.TY_ + (oy * p.s_out + py)) * p.TX_ +
+                                 (ox * p.s_out + px);
             base[sp] = act_apply(acc[i][j][r] + bv, p.act);
           }
         }
@@ -560,7 +579,7 @@ int launch_one(IgemmParams& p, int B, int nblk, hipStream_t st) {
   using C = IgemmCfg<S_IN, LO, HI, TZ, TY, RT, KC>;
   p.ntz = ceil_div(p.OZ, TZ), p.nty = ceil_div(p.OY, TY), p.ntx = ceil_div(p.OX, 32);
   auto kern = igemm_kernel<S_IN, LO, HI, TZ, TY, RT, KC>;
-  const size_t lds = C::lds_bytes(p.ntaps);
+  const size_t lds = C::lds_bytes(p.ncls > 0 ? 8 : p.ntaps);
   static thread_local size_t configured = 0;
   if (lds > configured) {
     SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -568,7 +587,7 @@ int launch_one(IgemmParams& p, int B, int nblk, hipStream_t st) {
   }
   p.grid_nblk = nblk;
   SR3D_CHECK((long long)p.ntz * p.nty * p.ntx * nblk < (1ll << 31) && B <= 65535, SR3D_E_ARG, "igemm: grid too large");
-  dim3 grid(p.ntz * p.nty * p.ntx * nblk, B, 1);
+  dim3 grid(p.ntz * p.nty * p.ntx * nblk, B, p.ncls > 0 ? p.ncls : 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
@@ -581,7 +600,12 @@ int launch(IgemmParams p, int B, const RowPlan& rp, const float* image, hipStrea
   if (sr3d_prof_active()) {
     // algorithmic FLOPs: 2 * taps * K * (valid rows) * output voxels (no padding counted)
     const double rows = p.epi == EPI_GATED ? 2.0 * p.Cg : (double)p.N;
-    const double flops = 2.0 * p.ntaps * p.K * rows * (double)p.OZ * p.OY * p.OX * B;
+    double flops = 2.0 * p.ntaps * p.K * rows * (double)p.OZ * p.OY * p.OX * B;
+    if (p.ncls > 0) {
+      flops = 0;
+      for (int c = 0; c < p.ncls; c++)
+        flops += 2.0 * p.cls[c].ntaps * p.K * rows * (double)p.cls[c].OZ * p.cls[c].OY * p.cls[c].OX * B;
+    }
     const int id = S_IN == 2 ? SR3D_PROF_IGEMM_S2 : (LO == 0 ? SR3D_PROF_IGEMM_BWD_S2 : SR3D_PROF_IGEMM_S1);
     sr3d_prof_begin(id, flops, st, &tok);
   }
@@ -596,6 +620,10 @@ int launch(IgemmParams p, int B, const RowPlan& rp, const float* image, hipStrea
   }
   if (rc == SR3D_OK && rp.rem > 0) {
     p.wp = image + region_floats(rp.nblk, p.nchunks, p.ntaps, rp.rt), p.n_off = rp.nblk * rp.rt * 32;
+    if (p.ncls > 0) {   // per class: region B follows region A inside the class's own image
+      p.wp = image;
+      for (int c = 0; c < p.ncls; c++) p.cls[c].wp_off += (long long)region_floats(rp.nblk, p.nchunks, p.cls[c].ntaps, rp.rt);
+    }
     switch (rp.rem) {
       case 1: rc = launch_one<S_IN, LO, HI, TZ, TY, 1, kKC>(p, B, 1, st); break;
       case 2: rc = launch_one<S_IN, LO, HI, TZ, TY, 2, kKC>(p, B, 1, st); break;
@@ -890,21 +918,24 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
   }
   using C = IgemmCfg<1, 0, 1, 2, 4, 4, kKC>;
+  // the 8 output-parity classes: packed one after the other, then ONE launch with blockIdx.z = class
+  p.ncls = 8, p.s_out = 2;
+  long long off = 0;
   for (int cls = 0; cls < 8; cls++) {
-    IgemmParams q = p;
+    IgemmParams::Cls& c = p.cls[cls];
     int dz[27], dy[27], dx[27];
-    pk.ntaps = q.ntaps = class_taps(cls, pk.tap, dz, dy, dx);
-    for (int t = 0; t < q.ntaps; t++) q.tap_off[t] = (dz[t] * C::HY + dy[t]) * C::HX + dx[t];
-    q.pz = (cls >> 2) & 1, q.py = (cls >> 1) & 1, q.px = cls & 1;
-    q.s_out = 2;
-    q.OZ = (d->Z - q.pz + 1) / 2, q.OY = (d->Y - q.py + 1) / 2, q.OX = (d->X - q.px + 1) / 2;
-    if (q.OZ > 0 && q.OY > 0 && q.OX > 0) {
-      if (int rc = run_pack(pk, rp, image, st)) return rc;
-      if (int rc = launch<1, 0, 1, 2, 4>(q, d->B, rp, image, st)) return rc;
-    }
-    image += image_floats(rp.units, p.nchunks, q.ntaps);
+    pk.ntaps = c.ntaps = class_taps(cls, pk.tap, dz, dy, dx);
+    for (int t = 0; t < c.ntaps; t++) c.tap_off[t] = (dz[t] * C::HY + dy[t]) * C::HX + dx[t];
+    c.pz = (cls >> 2) & 1, c.py = (cls >> 1) & 1, c.px = cls & 1;
+    c.OZ = (d->Z - c.pz + 1) / 2, c.OY = (d->Y - c.py + 1) / 2, c.OX = (d->X - c.px + 1) / 2;
+    c.wp_off = off;
+    if (c.OZ > 0 && c.OY > 0 && c.OX > 0)
+      if (int rc = run_pack(pk, rp, image + off, st)) return rc;
+    off += (long long)image_floats(rp.units, p.nchunks, c.ntaps);
   }
-  return SR3D_OK;
+  // grid of class 0 (even positions: the largest); ntaps of the launch-wide fields is only used for sizing
+  p.OZ = p.cls[0].OZ, p.OY = p.cls[0].OY, p.OX = p.cls[0].OX, p.ntaps = 8;
+  return launch<1, 0, 1, 2, 4>(p, d->B, rp, image, st);
 }
 
 }  // extern "C"
