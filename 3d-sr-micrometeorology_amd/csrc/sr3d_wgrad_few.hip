@@ -161,19 +161,23 @@ __global__ __launch_bounds__(256, F == 2 ? 2 : 1) void wgrad_few_kernel(const Fe
   }
 }
 
-// dw[m * ldw + (c0 + f) * 27 + t] = sum over the splits (fixed order)
+// dw[m * ldw + (c0 + f) * 27 + t] = sum over the splits.  One wave per output element: lane l adds splits l, l+64, ...
+// in order, then a fixed shuffle tree (deterministic); a single thread per element would walk up to 2048 splits
+// serially.
 __global__ __launch_bounds__(256) void wgrad_few_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                               int S, int M, int Mpad, int F, int few_n, int few_c0,
                                                               long long ldw) {
   const int total = M * F * 27;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= total) return;
   const int mm = e / (F * 27), ft = e - mm * (F * 27), f = ft / 27, t = ft - f * 27;
   if (f >= few_n) return;
   const float* src = slab + (long long)mm * (F * 27) + ft;
   float s = 0.f;
-  for (int k = 0; k < S; k++) s += src[(long long)k * Mpad * (F * 27)];
-  dw[(long long)mm * ldw + (few_c0 + f) * 27 + t] = s;
+  for (int k = lane; k < S; k += 64) s += src[(long long)k * Mpad * (F * 27)];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) dw[(long long)mm * ldw + (few_c0 + f) * 27 + t] = s;
 }
 
 struct FewPlan {
@@ -231,7 +235,7 @@ int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const 
   int rc = pl.F == 1 ? launch_few<1>(p, pl, st) : (pl.F == 2 ? launch_few<2>(p, pl, st) : launch_few<4>(p, pl, st));
   if (rc) return rc;
   const int total = M * pl.F * 27;
-  hipLaunchKernelGGL(wgrad_few_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float*)ws, dw, pl.S, M,
+  hipLaunchKernelGGL(wgrad_few_reduce_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, (const float*)ws, dw, pl.S, M,
                      pl.Mpad, pl.F, few_n, few_c0, ldw);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
