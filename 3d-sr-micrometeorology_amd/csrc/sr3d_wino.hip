@@ -37,8 +37,15 @@ namespace {
 constexpr int WKC = 2;                      // input channels per chunk
 constexpr int WPL = 3;                      // output planes per workgroup
 constexpr int WVP = WPL + 2;                // input planes per workgroup
-constexpr int WHY = 6, WHX = 34;            // halo rows x columns of one plane
-constexpr int WRE = WVP * WHY * WHX;        // 1020 raw floats per channel
+// Voxel tile of one plane = 32 Winograd tiles: 4 x 32 voxels (TS = 0) or 8 x 16 voxels (TS = 1, for the 80- and
+// 40-wide grids of the deeper U-Net levels, where 32-wide tiles would be 20 % / 60 % padding)
+template <int TS>
+struct WinoGeo {
+  static constexpr int TR = TS ? 4 : 2, TC = TS ? 8 : 16;   // tile rows x tile columns
+  static constexpr int VY = 2 * TR, VX = 2 * TC;            // voxels
+  static constexpr int HY = VY + 2, HX = VX + 2;            // halo rows x columns of one plane
+  static constexpr int RE = WVP * HY * HX;                  // raw floats per channel (1020 / 900)
+};
 constexpr int WRC = 1056;                   // raw channel pitch (== 32 mod 64: the two channels use disjoint banks)
 constexpr int WRB = WKC * WRC;              // raw buffer
 constexpr int WVB = WVP * 16 * WKC * 32;    // V buffer [plane][xi][c][tile]
@@ -60,8 +67,10 @@ __device__ __forceinline__ float wact(float v, int act) {
   return v;
 }
 
-template <int NRT>   // 32-row tiles per workgroup: 2, or 1 for a last block with <= 32 rows
+template <int NRT, int TS>   // NRT: 32-row tiles per workgroup (2, or 1 for a last block with <= 32 rows); TS: tile shape
 __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
+  using G = WinoGeo<TS>;
+  constexpr int WHY = G::HY, WHX = G::HX, WRE = G::RE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Vs = lds;                 // 2 buffers
   float* Us = lds + 2 * WVB;       // 2 buffers
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   const int tiy = blk % p.nty;
   const int tiz = blk / p.nty;
   const int b = blockIdx.y;
-  const int z0 = tiz * WPL, y0 = tiy * 4, x0 = tix * 32;
+  const int z0 = tiz * WPL, y0 = tiy * G::VY, x0 = tix * G::VX;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
   const int chan_bytes = (int)(ZYX * 4);
 
@@ -139,9 +148,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
 
   // ---- V transform, half a patch per thread: item q = (plane, half) is wave-uniform, lanes = (tile row, channel,
   // tile column).  half 0 produces xi_x = 0, 1 from patch columns 0, 1, 2; half 1 xi_x = 2, 3 from columns 2, 3, 1.
-  const int tty = lane >> 5, tch = (lane >> 4) & 1, ttx = lane & 15;
+  const int ttx = lane & (G::TC - 1), tch = (lane / G::TC) & 1, tty = lane / (2 * G::TC);
   const int t_rd = tch * WRC + (2 * tty) * WHX + 2 * ttx;
-  const int t_wr = tch * 32 + tty * 16 + ttx;
+  const int t_wr = tch * 32 + tty * G::TC + ttx;
   float vt[4][2];
   auto tv_read = [&](const float* R, const int q) {
     const int pl = q >> 1, h = q & 1;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   // (w & 1): it reduces its pair along x (2 values per element), the 8 waves' values meet in LDS.
   const int xh = wave & 1;
   const int er = tid >> 5, et = tid & 31;              // reader: rows er, er + 16 of the 32-row tile, tile et
-  const int ety = et >> 4, etx = et & 15;
+  const int ety = et / G::TC, etx = et & (G::TC - 1);
   const int oy = y0 + 2 * ety, ox = x0 + 2 * etx;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
   const bool pair_ok = (p.TX_ & 1) == 0 && p.pair_aligned;   // (x, x+1) pairs are 8-byte aligned in every destination
@@ -472,8 +481,23 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
   return SR3D_OK;
 }
 
+namespace {
+template <int NRT>
+void wino_launch_ts(int ts, dim3 grid, hipStream_t st, const SrWinoParams& p) {
+  if (ts)
+    hipLaunchKernelGGL((wino_kernel<NRT, 1>), grid, dim3(WNT), kWinoLds, st, p);
+  else
+    hipLaunchKernelGGL((wino_kernel<NRT, 0>), grid, dim3(WNT), kWinoLds, st, p);
+}
+}  // namespace
+
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
-  p.ntz = ceil_div(p.Z, WPL), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
+  // tile shape: 4 x 32 voxels, or 8 x 16 where that pads the (y, x) plane less (the 80- and 40-wide grids)
+  const long long pad0 = (long long)ceil_div(p.Y, 4) * 4 * ceil_div(p.X, 32) * 32;
+  const long long pad1 = (long long)ceil_div(p.Y, 8) * 8 * ceil_div(p.X, 16) * 16;
+  const int ts = pad1 < pad0 ? 1 : 0;
+  p.ntz = ceil_div(p.Z, WPL);
+  p.nty = ceil_div(p.Y, ts ? 8 : 4), p.ntx = ceil_div(p.X, ts ? 16 : 32);
   p.nchunks = ceil_div(p.K, WKC);
   {
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.save_f) | reinterpret_cast<uintptr_t>(p.save_s);
@@ -489,8 +513,10 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   SR3D_CHECK(p.K <= WCT, SR3D_E_ARG, "winograd conv: more than %d input channels", WCT);
   static thread_local bool configured = false;
   if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
     configured = true;
   }
   void* tok = nullptr;
@@ -504,16 +530,16 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   const int ntile32 = ceil_div(p.N, 32);
   if (nsp * (n2 + n1) < 160 && ntile32 > n2 + n1) {
     p.nblk = ntile32, p.nb_off = 0, p.rt_split = 1;
-    hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)(nsp * ntile32), B), dim3(WNT), kWinoLds, st, p);
+    wino_launch_ts<1>(ts, dim3((unsigned)(nsp * ntile32), B), st, p);
   } else {
     p.rt_split = 0;
     if (n2 > 0) {
       p.nblk = n2, p.nb_off = 0;
-      hipLaunchKernelGGL(wino_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(WNT), kWinoLds, st, p);
+      wino_launch_ts<2>(ts, dim3((unsigned)(nsp * n2), B), st, p);
     }
     if (n1 > 0) {
       p.nblk = 1, p.nb_off = n2;
-      hipLaunchKernelGGL(wino_kernel<1>, dim3((unsigned)nsp, B), dim3(WNT), kWinoLds, st, p);
+      wino_launch_ts<1>(ts, dim3((unsigned)nsp, B), st, p);
     }
   }
   sr3d_prof_end(tok, st);

@@ -205,6 +205,8 @@ def test_fullwidth_layers(eng):
     ((21, 4, 16), 1, 64, 64, None),
     # 32 k + 1..3 input channels: the odd channels take the few-channel weight-gradient kernel; odd K chunk
     ((5, 6, 16), 1, 33, 12, None), ((4, 8, 32), 1, 66, 40, None), ((3, 5, 18), 1, 35, 8, None),
+    # (y, x) extents where the Winograd kernel picks its 8 x 16-voxel tile shape (less padding than 4 x 32)
+    ((5, 40, 40), 1, 40, 72, None), ((4, 9, 20), 1, 33, 40, None), ((7, 24, 48), 1, 64, 64, None),
     # 64 k + 1..2 gradient rows on a grid of >= 500k voxels: the odd rows take the small-N VALU kernel
     ((16, 128, 256), 1, 65, 8, None), ((64, 128, 64), 1, 130, 4, None)])
 def test_odd_shapes_vs_oracle(eng, shape, stride, cin, cout, act):
