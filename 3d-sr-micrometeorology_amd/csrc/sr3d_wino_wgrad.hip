@@ -23,9 +23,16 @@
 
 namespace {
 
-constexpr int GT = 8;                       // Winograd tiles per strip (1 tile row x 8 tile columns)
-constexpr int GXW = 2 * GT + 2;             // raw input columns per row (18)
-constexpr int GXP = 4 * GXW + 2;            // raw X pitch per channel (74: even -> 8-byte aligned patch rows)
+constexpr int GT = 8;                       // Winograd tiles per strip: 1 x 8 tiles = 2 x 16 voxels (SS = 0), or
+                                            // 2 x 4 tiles = 4 x 8 voxels (SS = 1: 40- and 20-wide grids pad less)
+template <int SS>
+struct StripGeo {
+  static constexpr int VY = SS ? 4 : 2, VX = SS ? 8 : 16;   // voxels per strip
+  static constexpr int RW = VX + 2, RR = VY + 2;            // raw patch: RR rows x RW columns (4 x 18 / 6 x 10)
+  static constexpr int TC = SS ? 4 : 8;                     // tile columns
+};
+constexpr int GXP = 74;                     // raw X pitch per channel (>= 72, even -> 8-byte aligned patch rows,
+                                            // 2 * 37: the 32 channels of a b64 read hit 32 different bank pairs)
 constexpr int GNB = 64;                     // rows (output channels) per workgroup
 constexpr int GVS = 16 * GT * 32;           // one V plane slot: [xi][tile][32 c] floats
 // dM buffer: [xi] pitch 545 : [k-step (tile pair)] pitch 136 : [row tile] 64 : [tile parity] 32 : [n & 31].
@@ -56,7 +63,10 @@ __device__ __forceinline__ float dpp_xor8(float v) {   // value of lane ^ 8 (row
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
 }
 
+template <int SS>
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParams p) {
+  using SG = StripGeo<SS>;
+  constexpr int GXW = SG::RW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Vs = lds;                    // 4 slots [xi][tile][c]
   float* Ms = lds + 4 * GVS;          // 2 buffers
@@ -86,9 +96,10 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   // All global reads are raw BUFFER loads: the descriptor (scalar registers) covers exactly one channel plane
   // (x) / the group's rows of the sample (dY), so padding, ragged tiles, planes -1 and Z and channels beyond
   // Cin / N need no masks at all: their byte offset is out of range and the hardware returns 0.
+  constexpr int kRawE = SG::RR * GXW;   // 72 / 60 elements per channel: piece 0 = lanes 0..63, piece 1 the rest
   const int xr0 = lane / GXW, xc0 = lane - xr0 * GXW;
   const int xr1 = (64 + lane) / GXW, xc1 = (64 + lane) - xr1 * GXW;
-  const bool x1on = lane < 4 * GXW - 64;
+  const bool x1on = 64 + lane < kRawE;
   const int dn4 = lane >> 4, dr = (lane >> 3) & 1, dtl = lane & 7;
   // Base pointers of the current sample: wave-uniform (scalar registers), rebuilt when the batch index changes.
   // The 4 dY rows of a group sit in the same slice (slice widths are multiples of 4: host dispatch), so row i is
@@ -147,18 +158,18 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
       s_u = g_oz - 1, s_hi = g_oz + len, s_lo1 = g_oz + 1;
       t_next += len;
       if (g_b != s_b) set_batch(g_b), s_b = g_b;
-      const int y0 = g_tiy * 2, x0 = g_tix * (2 * GT);
+      const int y0 = g_tiy * SG::VY, x0 = g_tix * SG::VX;
       g_oz = 0;
       if (++g_tix == p.ntx) {
         g_tix = 0;
         if (++g_tiy == p.nty) g_tiy = 0, ++g_b;
       }
       const int gy0 = y0 - 1 + xr0, gx0 = x0 - 1 + xc0, gy1 = y0 - 1 + xr1, gx1 = x0 - 1 + xc1;
-      const bool ok0 = (unsigned)gy0 < (unsigned)p.Y && (unsigned)gx0 < (unsigned)p.X;
+      const bool ok0 = lane < kRawE && (unsigned)gy0 < (unsigned)p.Y && (unsigned)gx0 < (unsigned)p.X;
       const bool ok1 = x1on && (unsigned)gy1 < (unsigned)p.Y && (unsigned)gx1 < (unsigned)p.X;
       xoff0 = ok0 ? (unsigned)(gy0 * p.X + gx0) * 4u : kOob;
       xoff1 = ok1 ? (unsigned)(gy1 * p.X + gx1) * 4u : kOob;
-      const int gy = y0 + dr, gx = x0 + 2 * dtl;
+      const int gy = y0 + 2 * (dtl / SG::TC) + dr, gx = x0 + 2 * (dtl % SG::TC);
       const bool dok = gy < p.Y && gx < p.X;   // X is even (host dispatch): gx + 1 is valid with gx
       doffc = dok ? (unsigned)(dn4 * (int)ZYX + gy * p.X + gx) * 4u : kOob;
       n_valid = true;
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
           (void*)(xcur[k] + zo), 0, (zok && xcur[k] != nullptr) ? plane_bytes : 0, 0x00020000);
       float* row = buf + (wave + 8 * k) * GXP;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)row, 4, xoff0, 0, 0, 0);
-      if (x1on) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)(row + 64), 4, xoff1, 0, 0, 0);
+      if (kRawE > 64 && x1on) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_p)(row + 64), 4, xoff1, 0, 0, 0);
     }
   };
   // dY rows of the output completed by the step BEFORE the generator's current one (the generator runs two steps
@@ -224,7 +235,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   // columns 0, 1, 2), waves 4-7 xi_x = 2, 3 (from columns 2, 3 and 1); same code, different offsets and one sign.
   const int vh = wave >> 2;
   const int tc = tid & 31, ttl = (tid >> 5) & 7;
-  const int v_rd2 = tc * GXP + 2 * ttl + (vh ? 2 : 0), v_rd1 = tc * GXP + 2 * ttl + (vh ? 1 : 2);
+  const int v_rd0 = tc * GXP + 2 * (ttl / SG::TC) * GXW + 2 * (ttl % SG::TC);   // patch origin of tile ttl
+  const int v_rd2 = v_rd0 + (vh ? 2 : 0), v_rd1 = v_rd0 + (vh ? 1 : 2);
   const int v_wr = (2 * vh) * (GT * 32) + ttl * 32 + tc;
   const float vsign = vh ? -1.f : 1.f;
   float vt[4][2];
@@ -323,7 +335,10 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     __builtin_amdgcn_sched_barrier(0);
     // the rows of step s+1 (issued one step ago) have landed; younger loads (12 per wave) may stay in flight
     // (a bare s_barrier: __syncthreads() carries a release fence that would drain the younger LDS-DMA loads too)
-    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    if constexpr (kRawE > 64)
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else   // one x DMA per channel: 4 + 2 + 2 younger loads
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     prev_out = cur_out;
     cur_valid = nx_valid, cur_out = nx_out;
@@ -407,11 +422,19 @@ struct GPlan {
   long long ntiles, per_split;
 };
 
+// strip shape: 2 x 16 voxels, or 4 x 8 where that pads the (y, x) plane less
+int strip_shape(const sr3d_conv_desc_t* d) {
+  const long long pad0 = (long long)ceil_div(d->Y, 2) * 2 * ceil_div(d->X, 16) * 16;
+  const long long pad1 = (long long)ceil_div(d->Y, 4) * 4 * ceil_div(d->X, 8) * 8;
+  return pad1 < pad0 ? 1 : 0;
+}
+
 GPlan gplan(const sr3d_conv_desc_t* d, int n_total, int c_used) {
   GPlan g;
+  const int ss = strip_shape(d);
   g.nblk = ceil_div(n_total, GNB), g.cblk = ceil_div(c_used, 32);
   g.Npad = g.nblk * GNB, g.Cpad = g.cblk * 32;
-  g.nty = ceil_div(d->Y, 2), g.ntx = ceil_div(d->X, 2 * GT);
+  g.nty = ceil_div(d->Y, ss ? 4 : 2), g.ntx = ceil_div(d->X, ss ? 8 : 16);
   g.ntiles = (long long)d->B * g.nty * g.ntx * d->Z;
   // One workgroup per CU and every workgroup does the same amount of work: make the grid a whole number of rounds
   // over the 256 CUs (5 rounds if the slab cap allows it), otherwise as many splits as the cap allows.
@@ -448,13 +471,17 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   SR3D_CHECK(g.cblk <= 65535 && g.nblk <= 65535, SR3D_E_ARG, "winograd wgrad: too many blocks");
   static thread_local bool configured = false;
   if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
+    SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
     configured = true;
   }
   void* tok = nullptr;
   if (sr3d_prof_active())
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st, &tok);
-  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(g.S * g.cblk * g.nblk), dim3(512), kGLds, st, p);
+  if (strip_shape(d))
+    hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3(g.S * g.cblk * g.nblk), dim3(512), kGLds, st, p);
+  else
+    hipLaunchKernelGGL(wino_wgrad_kernel<0>, dim3(g.S * g.cblk * g.nblk), dim3(512), kGLds, st, p);
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
   const long long total = (long long)n_total * c_used * 3;
