@@ -198,6 +198,7 @@ def main():
                 traffic = {"hbm_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"] + t["write_bytes_per_launch"],
                            "fetch_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"],
                            "write_bytes_per_launch": t["write_bytes_per_launch"],
+                           "kernel_launches_per_step": t["launches_profiled"] / 2,   # a conv call may issue 2 launches
                            "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         per_kernel = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                           "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
