@@ -14,6 +14,13 @@ import torch
 from . import _lib as L
 
 
+# Test hook (tests/test_gpu_default_width.py): when set to a list, every fused activation appends the branch it took
+# per element (bool tensor on the CPU, in forward order).  The CPU oracle can then be evaluated with the SAME decisions
+# (oracle/ref_cpu.py:_act), which removes the only non-smooth step from a whole-model comparison.  Never set in
+# production code: it costs a device-to-host copy per layer.
+KINK_LOG: Optional[list] = None
+
+
 def _out_dim(z: int, s: int) -> int:
     return (z - 1) // s + 1
 
@@ -104,6 +111,8 @@ class Conv3dAct(torch.autograd.Function):
         L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.dev_ptr(wp),
                                       L.dev_ptr(bias, "bias"), L.dev_ptr(y), L.ACT_CODE[act], int(bool(unshuffle)),
                                       L.stream_ptr()), "sr3d_conv3d_fwd")
+        if KINK_LOG is not None and act is not None:
+            KINK_LOG.append((y > 0).cpu())
         ctx.desc, ctx.act, ctx.unshuffle, ctx.has_bias, ctx.nsrc = desc, act, unshuffle, bias is not None, len(srcs)
         ctx.save_for_backward(weight, y if act is not None else None, *srcs)
         return y
@@ -160,6 +169,8 @@ class GatedConv3dAct(torch.autograd.Function):
                                             L.dev_ptr(b_feat, "feature bias"), L.dev_ptr(b_gate, "gate bias"),
                                             L.dev_ptr(y), L.dev_ptr(sf), L.dev_ptr(ss), L.ACT_CODE[act],
                                             L.stream_ptr()), "sr3d_gated_conv3d_fwd")
+        if KINK_LOG is not None and act is not None:
+            KINK_LOG.append((sf > 0).cpu())
         ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
         ctx.save_for_backward(w_feat, w_gate, sf, ss, *srcs)
         return y

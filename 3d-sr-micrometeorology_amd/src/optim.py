@@ -12,33 +12,46 @@ import torch
 from .. import ops
 
 
+def flatten_parameters(params: Iterable[torch.nn.Parameter]):
+    """Re-point every trainable parameter to a view of ONE contiguous fp32 buffer and its ``.grad`` to a view of a
+    second one.  Offsets are multiples of 4 elements, so every view can be processed with 128-bit accesses.
+    Device-agnostic host logic (the gloo tests lay out the real 48-tensor model on the CPU with it).
+    Returns (params, offsets, flat_param, flat_grad)."""
+    plist: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+    if not plist:
+        raise ValueError("flatten_parameters: no trainable parameters")
+    dev = plist[0].device
+    offsets, off = [], 0
+    for p in plist:
+        if p.device != dev or p.dtype != torch.float32:
+            raise ValueError("flatten_parameters: parameters must be fp32 tensors on one device")
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+    flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        for p, o in zip(plist, offsets):
+            view = flat_param[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = flat_grad[o:o + p.numel()].view_as(p)
+    return plist, offsets, flat_param, flat_grad
+
+
 class FlatAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        if not self.params:
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("FlatAdam: no trainable parameters")
-        dev = self.params[0].device
-        if dev.type != "cuda":
+        if params[0].device.type != "cuda":
             raise RuntimeError("FlatAdam runs on the GPU only (move the model with .to('cuda') first)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.step_count = 0
         self.grad_scale = 1.0  # e.g. 1/world_size when gradients were SUM-all-reduced
-        # 16-byte aligned offsets so every view can be processed with 128-bit accesses
-        self.offsets, off = [], 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4
-        self.numel = off
-        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, o in zip(self.params, self.offsets):
-                view = self.flat_param[o:o + p.numel()].view_as(p)
-                view.copy_(p.data)
-                p.data = view
-                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self.params, self.offsets, self.flat_param, self.flat_grad = flatten_parameters(params)
+        self.numel = self.flat_param.numel()
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat_grad.zero_()

@@ -260,7 +260,82 @@ def fullwidth_fixture():
     print("fullwidth.npz")
 
 
+def _sampled(t, n_full=20000, n_samp=4096):
+    """small tensors whole, large ones as a strided sample of ~n_samp elements (start 0)"""
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= n_full:
+        return npy(flat)
+    return npy(flat[::_prime_step(flat.numel() // n_samp)])
+
+
+def _prime_step(n):
+    """smallest prime >= n: a stride that does not lock onto the (tap, channel) periods of a weight tensor"""
+    while any(n % q == 0 for q in range(2, int(n ** 0.5) + 1)):
+        n += 1
+    return n
+
+
+def default_width_fixture(name, hr, s, seed, mask_kind, loss_name):
+    """The reference's UNetSR at default.yml widths (65.47 M parameters) on a small grid.  The 262 MB of weights are
+    NOT stored: `torch.manual_seed(seed); make_model(cfg)` gives the same initial weights in the reference and in the
+    engine (tests/test_cabi_and_host.py pins that); an exact per-tensor checksum (int64 sum of the bit patterns) is stored to prove it.  Inputs come from
+    tests/helpers.py:synthetic_inputs with the stored seed.  Stored: prediction, loss values (L1 and the four terms of
+    the mixed loss), dL/dpred, and for each of the 48 parameter gradients its fp64 norm plus the whole tensor (small
+    ones) or a strided sample (large ones), in fp32 and from an fp64 run of the reference."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_inputs
+    cfg = yaml.safe_load(open(os.path.join(REF, "config", "default.yml")))
+    cfg["model"]["num_x2upsample"] = {2: 1, 4: 2}[s]
+    if loss_name == "L1":
+        cfg["train"]["loss"] = {"name": "L1"}
+    torch.manual_seed(seed)
+    model = make_model(cfg)
+    x, b, y = synthetic_inputs(1, hr, s, seed + 1, mask_kind)
+    out = {"config_json": np.array(json.dumps(cfg)),
+           "meta": np.array(json.dumps(dict(hr=hr, s=s, seed=seed, mask_kind=mask_kind, loss=loss_name)))}
+    for k, v in model.state_dict().items():
+        out["sdsum/" + k] = np.array(int(v.view(torch.int32).to(torch.int64).sum()), dtype=np.int64)   # order-independent
+    pred = model(x, b)
+    out["pred"] = npy(pred)
+    cm = yaml.safe_load(open(os.path.join(REF, "config", "default.yml")))
+    lf = make_loss(cm)
+    p = pred.detach().clone().requires_grad_(True)
+    terms = lf.calc_loss_terms(predicts=p, targets=y, masks=b)
+    total = lf(p, y, b)
+    total.backward()
+    out["loss/mixed/terms"] = np.array([float(t) for t in terms], dtype=np.float64)
+    out["loss/mixed/total"] = np.array(float(total), dtype=np.float64)
+    if loss_name != "L1":
+        out["loss/mixed/dpred"] = npy(p.grad)
+    out["loss/l1/total"] = np.array(float((pred - y).abs().mean()), dtype=np.float64)
+
+    model.zero_grad()
+    loss = make_loss(cfg)(model(x, b), y, b)
+    loss.backward()
+    out["train_loss"] = np.array(float(loss), dtype=np.float64)
+    for k, v in model.named_parameters():
+        out["gradnorm/" + k] = np.array(float(v.grad.double().norm()), dtype=np.float64)
+        out["grad/" + k] = _sampled(v.grad)
+
+    m64 = make_model(cfg).double()
+    m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    p64 = m64(x.double(), b.double())
+    l64 = make_loss(cfg)(p64, y.double(), b.double())
+    l64.backward()
+    out["f64/pred_s4"] = npy(p64.reshape(-1)[::4]).astype(np.float32)   # every 4th element
+    out["f64/train_loss"] = np.array(float(l64), dtype=np.float64)
+    for k, v in m64.named_parameters():
+        out["f64/gradnorm/" + k] = np.array(float(v.grad.norm()), dtype=np.float64)
+        out["f64/grad/" + k] = _sampled(v.grad).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "pred", tuple(pred.shape), "loss", float(loss), "f64", float(l64))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "default_width":   # only the (slow) default-width fixtures
+        default_width_fixture("model_default_a.npz", (16, 64, 64), 4, 31, "tower", "MixedDivergenceGradientL2Loss")
+        default_width_fixture("model_default_b.npz", (32, 64, 64), 2, 32, "iid", "L1")
+        sys.exit(0)
     cfg_a = base_config()  # num_x2upsample = 2
     model_fixture("model_tiny_a.npz", cfg_a, 2, (16, 16, 16), 21, "iid")
     cfg_b = base_config()

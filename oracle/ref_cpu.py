@@ -67,9 +67,25 @@ def shuffle_voxels(x: Tensor, factor: int = 2) -> Tensor:
 # --------------------------------------------------------------------------
 # convolution building blocks  (pytorch/model/custom_conv.py:77-126, 237-306)
 # --------------------------------------------------------------------------
-def _act(name: Optional[str], x: Tensor) -> Tensor:
+class KinkRecorder(list):
+    """pass as ``kinks`` to RECORD the oracle's own activation decisions (in the format the forced mode consumes)"""
+
+
+def _act(name: Optional[str], x: Tensor, kinks=None) -> Tensor:
+    """activation; with ``kinks`` (an iterator of boolean masks, one per activation in forward order) the branch of
+    every element is FORCED to the given decision instead of being taken from the sign of x.  Test-only: two correct
+    fp32 evaluations disagree about the branch of pre-activations within rounding distance of 0, and at default
+    widths a handful of such disagreements moves parameter gradients by up to 1e-3; forcing the HIP path's decisions
+    into the oracle makes both sides the same smooth function, which can then be compared at 1e-5."""
     if name is None:
         return x
+    if isinstance(kinks, KinkRecorder):
+        kinks.append(x.detach() > 0)
+    elif kinks is not None:
+        m = next(kinks).to(device=x.device, dtype=x.dtype)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        slope = {"relu": 0.0, "lrelu": 0.01}[name]
+        return x * (m + slope * (1 - m))
     if name == "relu":
         return F.relu(x)
     if name == "lrelu":  # nn.LeakyReLU() default slope 0.01
@@ -78,7 +94,7 @@ def _act(name: Optional[str], x: Tensor) -> Tensor:
 
 
 def conv_with_act(sd: StateDict, prefix: str, x: Tensor, stride: int,
-                  conv_mode: Optional[str], act: Optional[str]) -> Tensor:
+                  conv_mode: Optional[str], act: Optional[str], kinks=None) -> Tensor:
     """``MyConvWithAct2.forward`` (pytorch/model/custom_conv.py:111-126).
 
     ``conv_mode is None``: act(conv3d(x)).  Gated modes
@@ -89,35 +105,41 @@ def conv_with_act(sd: StateDict, prefix: str, x: Tensor, stride: int,
     if conv_mode is None:
         y = F.conv3d(x, sd[prefix + ".conv.weight"], sd.get(prefix + ".conv.bias"),
                      stride=stride, padding=1)
-        return _act(act, y)
+        return _act(act, y, kinks)
     if conv_mode in ("g_conv", "g_conv_with_separated_bias"):
         feat = F.conv3d(x, sd[prefix + ".conv.conv3d.weight"],
                         sd.get(prefix + ".conv.conv3d.bias"), stride=stride, padding=1)
         gate = F.conv3d(x, sd[prefix + ".conv.mask_conv3d.weight"],
                         sd.get(prefix + ".conv.mask_conv3d.bias"), stride=stride, padding=1)
-        return torch.sigmoid(gate) * _act(act, feat)
+        return torch.sigmoid(gate) * _act(act, feat, kinks)
     raise NotImplementedError(f"{conv_mode} is not supported.")
 
 
 def down_block(sd: StateDict, prefix: str, x: Tensor, conv_mode: Optional[str],
-               n_layers: int) -> Tensor:
+               n_layers: int, kinks=None) -> Tensor:
     """``DownBlock`` (pytorch/model/unet.py:13-55): stride-2 conv then
     ``n_layers-1`` stride-1 convs, all with ReLU."""
-    y = conv_with_act(sd, f"{prefix}.convs.0", x, 2, conv_mode, "relu")
+    y = conv_with_act(sd, f"{prefix}.convs.0", x, 2, conv_mode, "relu", kinks)
     for i in range(1, n_layers):
-        y = conv_with_act(sd, f"{prefix}.convs.{i}", y, 1, conv_mode, "relu")
+        y = conv_with_act(sd, f"{prefix}.convs.{i}", y, 1, conv_mode, "relu", kinks)
     return y
 
 
 def up_block(sd: StateDict, prefix: str, x1: Tensor, x2: Tensor,
-             conv_mode: Optional[str], n_layers: int) -> Tensor:
+             conv_mode: Optional[str], n_layers: int, kinks=None) -> Tensor:
     """``UpBlock`` (pytorch/model/unet.py:58-115): x3 = unshuffle(lrelu(conv(x1)+b));
     y = cat[x2, x3]; n_layers x lrelu(conv(y))."""
     u = F.conv3d(x1, sd[f"{prefix}.up.0.weight"], sd[f"{prefix}.up.0.bias"], padding=1)
-    x3 = unshuffle_voxels(F.leaky_relu(u, 0.01), 2)
+    if kinks is None:
+        x3 = unshuffle_voxels(F.leaky_relu(u, 0.01), 2)
+    elif isinstance(kinks, KinkRecorder):
+        x3 = unshuffle_voxels(F.leaky_relu(u, 0.01), 2)
+        kinks.append(x3.detach() > 0)
+    else:   # the decision mask is given in the unshuffled layout (that is what the fused kernel writes)
+        x3 = unshuffle_voxels(_act("lrelu", u, iter([shuffle_voxels(next(kinks).float(), 2)])), 2)
     y = torch.cat([x2, x3], dim=1)
     for i in range(n_layers):
-        y = conv_with_act(sd, f"{prefix}.convs.{i}", y, 1, conv_mode, "lrelu")
+        y = conv_with_act(sd, f"{prefix}.convs.{i}", y, 1, conv_mode, "lrelu", kinks)
     return y
 
 
@@ -126,7 +148,7 @@ def avg_pool_mask(b: Tensor) -> Tensor:
     return F.avg_pool3d(b, kernel_size=2, stride=2)
 
 
-def unet_forward(sd: StateDict, model_cfg: dict, x: Tensor, b: Tensor) -> Tensor:
+def unet_forward(sd: StateDict, model_cfg: dict, x: Tensor, b: Tensor, kinks=None) -> Tensor:
     """``UNetSR.forward`` (pytorch/model/unet.py:253-297), functional form.
 
     ``model_cfg`` is the ``model:`` section of the reference YAML
@@ -143,37 +165,43 @@ def unet_forward(sd: StateDict, model_cfg: dict, x: Tensor, b: Tensor) -> Tensor
     # nearest upsample (unet.py:143,254): x0[z,y,x] = x[z//s, y//s, x//s]
     x0 = x.repeat_interleave(s, 2).repeat_interleave(s, 3).repeat_interleave(s, 4)
     x0 = torch.cat([x0, b], 1)
-    y0 = torch.cat([conv_with_act(sd, "conv0", x0, 1, cm0, None), b], 1)
+    forced = kinks is not None and not isinstance(kinks, KinkRecorder)
+    if forced:
+        kinks = iter(kinks)
+    y0 = torch.cat([conv_with_act(sd, "conv0", x0, 1, cm0, None, kinks), b], 1)
 
     b1 = avg_pool_mask(b)
-    y1 = torch.cat([down_block(sd, "down1", y0, cmd, nlb), b1], 1)
+    y1 = torch.cat([down_block(sd, "down1", y0, cmd, nlb, kinks), b1], 1)
     b2 = avg_pool_mask(b1)
-    y2 = torch.cat([down_block(sd, "down2", y1, cmd, nlb), b2], 1)
+    y2 = torch.cat([down_block(sd, "down2", y1, cmd, nlb, kinks), b2], 1)
     b3 = avg_pool_mask(b2)
-    y3 = torch.cat([down_block(sd, "down3", y2, cmd, nlb), b3], 1)
+    y3 = torch.cat([down_block(sd, "down3", y2, cmd, nlb, kinks), b3], 1)
 
     def latent(t: Tensor) -> Tensor:
         # unet.py:192-199: Conv3d(bias=False) + LeakyReLU, num_latent_layers times
         for i in range(int(model_cfg["num_latent_layers"])):
-            t = F.leaky_relu(F.conv3d(t, sd[f"latent_layers.{2 * i}.weight"], None, padding=1), 0.01)
+            t = _act("lrelu", F.conv3d(t, sd[f"latent_layers.{2 * i}.weight"], None, padding=1), kinks)
         return t
 
     if not has4:
         y = latent(y3)
     else:
         b4 = avg_pool_mask(b3)
-        y4 = torch.cat([down_block(sd, "down4", y3, cmd, nlb), b4], 1)
+        y4 = torch.cat([down_block(sd, "down4", y3, cmd, nlb, kinks), b4], 1)
         y = torch.cat([latent(y4), b4], 1)
-        y = up_block(sd, "up4", y, y3, cmu, nlb)
+        y = up_block(sd, "up4", y, y3, cmu, nlb, kinks)
 
     y = torch.cat([y, b3], 1)
-    y = up_block(sd, "up3", y, y2, cmu, nlb)
+    y = up_block(sd, "up3", y, y2, cmu, nlb, kinks)
     y = torch.cat([y, b2], 1)
-    y = up_block(sd, "up2", y, y1, cmu, nlb)
+    y = up_block(sd, "up2", y, y1, cmu, nlb, kinks)
     y = torch.cat([y, b1], 1)
-    y = up_block(sd, "up1", y, y0, cmu, nlb)
+    y = up_block(sd, "up1", y, y0, cmu, nlb, kinks)
     y = torch.cat([y, x0], 1)
-    return F.conv3d(y, sd["last.weight"], sd["last.bias"], padding=1)
+    out = F.conv3d(y, sd["last.weight"], sd["last.bias"], padding=1)
+    if forced:
+        assert next(kinks, None) is None, "more activation decisions were recorded than the model has activations"
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -410,15 +438,19 @@ class AdamState:
             p.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
-def loss_and_grads(sd: StateDict, config: dict, x: Tensor, b: Tensor, t: Tensor):
+def loss_and_grads(sd: StateDict, config: dict, x: Tensor, b: Tensor, t: Tensor, kinks=None, l1_sign=None):
     """forward + loss + backward of one batch (the body of
     pytorch/src/optim_helper.py:42-47 without the optimizer step).
 
-    Returns (pred, loss, dL/dpred, {name: grad})."""
+    ``kinks`` / ``l1_sign`` (test-only, see :func:`_act`): forced activation decisions, and for the L1 loss the forced
+    sign(p - t) field.  Returns (pred, loss, dL/dpred, {name: grad})."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-    pred = unet_forward(leaves, config["model"], x, b)
+    pred = unet_forward(leaves, config["model"], x, b, kinks)
     pred.retain_grad()
-    loss = make_loss(config)(pred, t, b)
+    if l1_sign is not None and config["train"]["loss"]["name"] == "L1":
+        loss = ((pred - t) * l1_sign.to(pred.dtype)).mean()
+    else:
+        loss = make_loss(config)(pred, t, b)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return pred.detach(), loss.detach(), pred.grad.detach(), grads

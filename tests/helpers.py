@@ -35,3 +35,37 @@ def relerr(a, b):
     den = float(b.norm())
     num = float((a - b).norm())
     return num / den if den > 0 else num
+
+
+def tower_mask(Z, Y, X):
+    """deterministic 'buildings': boxes rising from z=0 (1 = fluid, 0 = building); same as oracle/make_golden.py"""
+    b = torch.ones(1, 1, Z, Y, X)
+    b[..., : Z // 2, Y // 4: Y // 4 + 3, X // 4: X // 4 + 5] = 0
+    b[..., : (3 * Z) // 4, Y // 2: Y // 2 + 4, X // 2: X // 2 + 2] = 0
+    b[..., :2, :2, -3:] = 0
+    return b
+
+
+def synthetic_inputs(B, hr, s, seed, mask_kind):
+    """seeded LR input, building mask and HR target (the recipe oracle/make_golden.py used for the fixtures whose
+    inputs are regenerated instead of stored)"""
+    g = torch.Generator().manual_seed(seed)
+    Z, Y, X = hr
+    x = torch.rand(B, 4, Z // s, Y // s, X // s, generator=g)
+    y = torch.rand(B, 4, Z, Y, X, generator=g)
+    if mask_kind == "iid":
+        b = (torch.rand(B, 1, Z, Y, X, generator=g) > 0.2).float()
+    else:
+        b = tower_mask(Z, Y, X).repeat(B, 1, 1, 1, 1)
+    return x, b, y
+
+
+def sampled(t, n_full=20000, n_samp=4096):
+    """the sampling oracle/make_golden.py:_sampled applied to large gradients"""
+    flat = torch.as_tensor(t).detach().reshape(-1)
+    if flat.numel() <= n_full:
+        return flat
+    n = flat.numel() // n_samp
+    while any(n % q == 0 for q in range(2, int(n ** 0.5) + 1)):      # smallest prime >= n, as in make_golden.py
+        n += 1
+    return flat[::n]

@@ -1,0 +1,125 @@
+"""Data-parallel path on the GPU box (one MI355X): RCCL with a single rank (initialisation, broadcast, bucketed
+all-reduce on the side stream, Adam with the folded 1/world factor), and the engine's 2-rank gradient equality --
+two processes sharing cuda:0, each with half of a global batch, against one process with the whole batch
+(SURVEY.md section 4 item 4).  Two ranks cannot share one GPU under RCCL, so that test moves the buckets with the
+gloo backend; the reducer code (hooks, buckets, side stream, finish) is the same.  No scaling number comes out of
+this file: it checks values only."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import T, cfg_of, load_golden, relerr, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _l1_cfg(d):
+    cfg = cfg_of(d)
+    cfg["train"]["loss"] = {"name": "L1"}
+    return cfg
+
+
+def _step(eng, cfg, sd, x, b, y, reducer_factory=None, bucket_bytes=None):
+    model = eng.make_model(cfg)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    opt = eng.FlatAdam(model.parameters(), lr=1e-3)
+    red = None
+    if reducer_factory is not None:
+        red = reducer_factory(opt)
+        red.broadcast_parameters(opt.flat_param)
+    loss = eng.make_loss(cfg)(model(x.to(DEV), b.to(DEV)), y.to(DEV), b.to(DEV))
+    opt.zero_grad()
+    loss.backward()
+    if red is not None:
+        opt.grad_scale = red.finish()
+    grads = (opt.flat_grad * opt.grad_scale).clone()
+    opt.step()
+    torch.cuda.synchronize()
+    if red is not None:
+        red.remove_hooks()
+    return float(loss.detach()), grads.cpu(), opt.flat_param.detach().clone().cpu(), (len(red.buckets) if red else 0)
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))     # nccl == RCCL on ROCm
+    import sr3d_amd as eng
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = _l1_cfg(d), sub(d, "sd")
+    x, b, y = T(d["x"]), T(d["b"]), T(d["y"])
+    plain = _step(eng, cfg, sd, x, b, y)
+    # 4 KB buckets: every parameter its own bucket -> 46 asynchronous all-reduces on the side stream
+    ddp = _step(eng, cfg, sd, x, b, y, lambda opt: eng.GradAllReducer(opt.params, opt.flat_grad, opt.offsets,
+                                                                      bucket_bytes=4096))
+    q.put({"loss_equal": plain[0] == ddp[0], "grads_equal": bool(torch.equal(plain[1], ddp[1])),
+           "params_equal": bool(torch.equal(plain[2], ddp[2])), "buckets": ddp[3],
+           "backend": dist.get_backend()})
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_walks_the_whole_ddp_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out["backend"] == "nccl" and out["buckets"] >= 40, out
+    assert out["loss_equal"] and out["grads_equal"] and out["params_equal"], out
+
+
+def _two_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sr3d_amd as eng
+    d = load_golden("model_tiny_a.npz")                       # global batch of 2 samples
+    cfg, sd = _l1_cfg(d), sub(d, "sd")
+    x, b, y = T(d["x"]), T(d["b"]), T(d["y"])
+    if rank != 0:                                             # the broadcast must repair this
+        sd = {k: torch.zeros_like(v) for k, v in sd.items()}
+    out = _step(eng, cfg, sd, x[rank:rank + 1], b[rank:rank + 1], y[rank:rank + 1],
+                lambda opt: eng.GradAllReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=64 << 10))
+    q.put((rank, (out[0], out[1].numpy(), out[2].numpy(), out[3])))   # numpy: pickled by value, no fd passing
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_the_same_global_batch():
+    import sr3d_amd as eng
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = _l1_cfg(d), sub(d, "sd")
+    whole = _step(eng, cfg, sd, T(d["x"]), T(d["b"]), T(d["y"]))          # one process, batch 2
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    out = {r: (o[0], torch.from_numpy(o[1]), torch.from_numpy(o[2]), o[3]) for r, o in out.items()}
+    # mean |p - t| over 2 samples = mean of the per-sample means: averaged rank gradients = whole-batch gradient
+    assert abs(0.5 * (out[0][0] + out[1][0]) - whole[0]) < 1e-6 * whole[0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])     # ranks agree bit for bit
+    assert relerr(out[0][1], whole[1]) < 1e-5
+    assert relerr(out[0][2], whole[2]) < 1e-5               # parameters after the Adam step
+    assert out[0][3] > 5

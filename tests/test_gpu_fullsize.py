@@ -105,11 +105,13 @@ def test_unshuffle_conv_full_level1(eng):
     assert relerr(got, ref) < TOL
 
 
-def test_losses_at_full_size(eng):
+@pytest.mark.parametrize("B", [1, 4])
+def test_losses_at_full_size(eng, B):
+    """B = 4 is the batch of BASELINE configs[2] (80x320x320, physics loss)"""
     g = torch.Generator().manual_seed(3)
-    p = torch.rand(1, 4, *FULL, generator=g)
-    t = torch.rand(1, 4, *FULL, generator=g)
-    b = (torch.rand(1, 1, *FULL, generator=g) > 0.2).float()
+    p = torch.rand(B, 4, *FULL, generator=g)
+    t = torch.rand(B, 4, *FULL, generator=g)
+    b = (torch.rand(B, 1, *FULL, generator=g) > 0.2).float()
     scales = [14.4, 21.6, 7.0]
     pd = p.to(DEV).requires_grad_(True)
     terms = eng.ops.MixedLossFn.apply(pd, t.to(DEV), b.to(DEV), scales, 5.0, 1.0, 10.0)
@@ -119,7 +121,7 @@ def test_losses_at_full_size(eng):
     ref_total = ref_terms[0] + 1.0 * ref_terms[1] + 10.0 * ref_terms[2]
     ref_total.backward()
     for a, r in zip(terms[:3].tolist(), ref_terms):
-        assert abs(a - float(r)) < TOL * abs(float(r))
+        assert abs(a - float(r.detach())) < TOL * abs(float(r.detach()))
     assert abs(float(terms[3]) - float(ref_total)) < TOL * float(ref_total)
     assert relerr(pd.grad, pr.grad) < TOL
     pd2 = p.to(DEV).requires_grad_(True)
@@ -127,6 +129,86 @@ def test_losses_at_full_size(eng):
     l1.backward()
     assert abs(float(l1) - float((p - t).abs().mean())) < TOL * float(l1)
     assert relerr(pd2.grad, torch.sign(p - t) / p.numel()) < 1e-6
+
+
+def test_batch4_gated_stride2_full_size(eng):
+    """down1.convs.0 of BASELINE configs[2]: gated 65 -> 128, stride 2, batch 4 at 80x320x320 (virtual concat of a
+    64-channel tensor and the mask).  Windows of the LAST sample against the oracle on the cropped input."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    B, ca, cout = 4, 64, 128
+    xa = torch.rand(B, ca, *FULL, generator=g, device=DEV) - 0.5
+    xb = (torch.rand(B, 1, *FULL, generator=g, device=DEV) > 0.2).float()
+    wf = torch.randn(cout, ca + 1, 3, 3, 3, generator=g, device=DEV) * 0.05
+    wg = torch.randn(cout, ca + 1, 3, 3, 3, generator=g, device=DEV) * 0.05
+    bg = torch.randn(cout, generator=g, device=DEV) * 0.1
+    y = eng.ops.gated_conv3d_act([xa, xb], wf, wg, None, bg, act="relu", stride=2)
+    assert tuple(y.shape) == (B, cout, 40, 160, 160)
+    wfc, wgc, bgc = wf.cpu(), wg.cpu(), bg.cpu()
+    for smp in (0, B - 1):
+        for lo, hi in [((0, 0, 0), (3, 5, 20)), ((36, 150, 128), (40, 160, 160)), ((17, 77, 45), (20, 82, 78))]:
+            ilo = [max(0, 2 * l - 1) for l in lo]
+            ihi = [min(f, 2 * (h - 1) + 2) for h, f in zip(hi, FULL)]
+            xc = torch.cat([_crop(xa[smp:smp + 1], ilo, ihi), _crop(xb[smp:smp + 1], ilo, ihi)], 1).cpu()
+            pad = []
+            for dd in (2, 1, 0):
+                pad += [1 if 2 * lo[dd] - 1 < 0 else 0, 1 if 2 * (hi[dd] - 1) + 2 > FULL[dd] else 0]
+            xc = F.pad(xc, pad)
+            ref = torch.sigmoid(F.conv3d(xc, wgc, bgc, stride=2)) * F.relu(F.conv3d(xc, wfc, None, stride=2))
+            got = _crop(y[smp:smp + 1], lo, hi).cpu()
+            assert got.shape == ref.shape
+            assert relerr(got, ref) < TOL, (smp, lo)
+
+
+def test_batch4_unshuffle_conv_beyond_2g_elements(eng):
+    """up1.up.0 of BASELINE configs[2]: 129 -> 1032 + bias + LeakyReLU + voxel unshuffle at batch 4; the output
+    (4, 129, 80, 320, 320) has 4.2e9 elements, so the last sample sits beyond 2^31 ELEMENTS (not just bytes).
+    Forward windows, and -- with dy supported in a window of the last sample -- input and weight gradients."""
+    g = torch.Generator(device=DEV).manual_seed(22)
+    B, ca = 4, 128
+    lr_grid = (40, 160, 160)
+    xa = (torch.rand(B, ca, *lr_grid, generator=g, device=DEV) - 0.5).requires_grad_(True)
+    xb = (torch.rand(B, 1, *lr_grid, generator=g, device=DEV) > 0.2).float()
+    w = (torch.randn(8 * (ca + 1), ca + 1, 3, 3, 3, generator=g, device=DEV) * 0.03).requires_grad_(True)
+    bias = (torch.randn(8 * (ca + 1), generator=g, device=DEV) * 0.1).requires_grad_(True)
+    y = eng.ops.conv3d_act([xa, xb], w, bias, act="lrelu", unshuffle=True)
+    assert tuple(y.shape) == (B, ca + 1, *FULL) and y.numel() > 2 ** 31
+    wc, bc = w.detach().cpu(), bias.detach().cpu()
+    smp = B - 1
+    lo, hi = (30, 150, 120), (34, 156, 154)                  # coarse window of the last sample, interior
+    ilo, ihi = [l - 1 for l in lo], [h + 1 for h in hi]
+    xc = torch.cat([_crop(xa[smp:smp + 1].detach(), ilo, ihi), _crop(xb[smp:smp + 1], ilo, ihi)], 1).cpu()
+    xcr, wcr, bcr = xc.clone().requires_grad_(True), wc.clone().requires_grad_(True), bc.clone().requires_grad_(True)
+    pre = F.conv3d(xcr, wcr, bcr)
+    ref = R.unshuffle_voxels(F.leaky_relu(pre, 0.01), 2)
+    got = _crop(y[smp:smp + 1].detach(), [2 * l for l in lo], [2 * h for h in hi]).cpu()
+    assert relerr(got, ref) < TOL
+    # also the first voxels of sample 0 and the last voxels of the last sample (the far end of the 17 GB tensor)
+    for s2, lo2, hi2 in [(0, (0, 0, 0), (2, 3, 18)), (smp, (38, 157, 140), (40, 160, 160))]:
+        i0 = [max(0, l - 1) for l in lo2]
+        i1 = [min(f, h + 1) for h, f in zip(hi2, lr_grid)]
+        x2 = torch.cat([_crop(xa[s2:s2 + 1].detach(), i0, i1), _crop(xb[s2:s2 + 1], i0, i1)], 1).cpu()
+        pad = []
+        for dd in (2, 1, 0):
+            pad += [1 if lo2[dd] - 1 < 0 else 0, 1 if hi2[dd] + 1 > lr_grid[dd] else 0]
+        r2 = R.unshuffle_voxels(F.leaky_relu(F.conv3d(F.pad(x2, pad), wc, bc), 0.01), 2)
+        g2 = _crop(y[s2:s2 + 1].detach(), [2 * l for l in lo2], [2 * h for h in hi2]).cpu()
+        assert relerr(g2, r2) < TOL, (s2, lo2)
+
+    # backward: dy lives in the fine-grid window of the last sample only, and not on elements next to the kink
+    dyc = (torch.rand(ref.shape) - 0.5) * R.unshuffle_voxels((pre.detach().abs() > 1e-5).float(), 2)
+    ref.backward(dyc)
+    dy = torch.zeros_like(y)
+    dy[smp:smp + 1, :, 2 * lo[0]:2 * hi[0], 2 * lo[1]:2 * hi[1], 2 * lo[2]:2 * hi[2]] = dyc.to(DEV)
+    y.backward(dy)
+    del dy, y
+    dx = xa.grad
+    assert float(dx[:smp].abs().max()) == 0.0
+    outside = dx[smp:smp + 1].clone()
+    outside[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1], ilo[2]:ihi[2]] = 0
+    assert float(outside.abs().max()) == 0.0
+    assert relerr(_crop(dx[smp:smp + 1], ilo, ihi), xcr.grad[:, :ca]) < TOL
+    assert relerr(w.grad, wcr.grad) < TOL
+    assert relerr(bias.grad, bcr.grad) < TOL
 
 
 def test_fused_adam_65m_parameters(eng):

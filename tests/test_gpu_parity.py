@@ -1,9 +1,9 @@
 """HIP path vs golden vectors / CPU oracle -- run on the MI355X box (pytest -m gpu).
 
 Tolerances are NORMWISE relative errors ||a-b||/||b||:
-1e-5 for activations/predictions/losses as BASELINE.json's north_star states;
-parameter gradients get 5e-5 because the reference's own fp32-vs-fp64 noise on
-them is already up to 5e-6."""
+1e-5 for activations/predictions/losses AND parameter gradients, as BASELINE.json's
+north_star states (the reference's own fp32-vs-fp64 noise on parameter gradients is
+up to 5e-6; the worst seen from the HIP path is 3e-6)."""
 import json
 
 import numpy as np
@@ -15,7 +15,7 @@ from helpers import T, cfg_of, load_golden, relerr, sub
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-TOL_G = 5e-5
+TOL_G = 1e-5
 
 
 @pytest.fixture(scope="module")
