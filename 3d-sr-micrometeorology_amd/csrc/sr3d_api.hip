@@ -33,56 +33,69 @@ int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channe
 }
 
 // ---- optional per-kernel timing with HIP events (bench.py roofline leg) ------------
+// The event pairs are created by sr3d_profile_enable(1), i.e. OUTSIDE the timed region; a launch only records two
+// of them.  When the pool is used up further launches are counted as dropped (bench.py reports it).
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int id; };
+struct ProfRec { hipEvent_t a, b; double work; int id; bool used; };
+constexpr int kProfPool = 16384;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
+int g_prof_next = 0;
+long long g_prof_dropped = 0;
 bool g_prof_on = false;
 }  // namespace
 
 bool sr3d_prof_active() { return g_prof_on; }
 
-void sr3d_prof_begin(int id, double flops, hipStream_t st, void** token) {
+void sr3d_prof_begin(int id, double work, hipStream_t st, void** token) {
   *token = nullptr;
   if (!g_prof_on) return;
-  ProfRec* r = new ProfRec{nullptr, nullptr, flops, id};
-  if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
-  (void)hipEventRecord(r->a, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_next >= (int)g_prof.size()) { g_prof_dropped++; return; }
+  ProfRec* r = &g_prof[g_prof_next++];
+  r->work = work, r->id = id, r->used = false;
+  if (hipEventRecord(r->a, st) != hipSuccess) return;
   *token = r;
 }
 
 void sr3d_prof_end(void* token, hipStream_t st) {
   if (!token) return;
   ProfRec* r = (ProfRec*)token;
-  (void)hipEventRecord(r->b, st);
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back(*r);
-  delete r;
+  r->used = hipEventRecord(r->b, st) == hipSuccess;
 }
 
 extern "C" {
 int sr3d_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  g_prof.clear();
+  g_prof_next = 0, g_prof_dropped = 0;
+  if (on && g_prof.empty()) {
+    g_prof.reserve(kProfPool);
+    for (int i = 0; i < kProfPool; i++) {
+      ProfRec r{nullptr, nullptr, 0.0, -1, false};
+      if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) break;
+      g_prof.push_back(r);
+    }
+  }
   g_prof_on = on != 0;
   return SR3D_OK;
 }
 
-int sr3d_profile_read(int kernel_id, double* ms, double* flops, long long* launches) {
-  SR3D_CHECK(ms && flops && launches, SR3D_E_ARG, "profile_read: null pointer");
+int sr3d_profile_read(int kernel_id, double* ms, double* work, long long* launches) {
+  SR3D_CHECK(ms && work && launches, SR3D_E_ARG, "profile_read: null pointer");
   std::lock_guard<std::mutex> lk(g_prof_mu);
   double t = 0, f = 0; long long n = 0;
-  for (auto& r : g_prof) {
-    if (r.id != kernel_id) continue;
+  if (kernel_id == SR3D_PROF_DROPPED) { *ms = 0, *work = 0, *launches = g_prof_dropped; return SR3D_OK; }
+  for (int i = 0; i < g_prof_next; i++) {
+    ProfRec& r = g_prof[i];
+    if (r.id != kernel_id || !r.used) continue;
     SR3D_HIP(hipEventSynchronize(r.b));
     float e = 0.f;
     SR3D_HIP(hipEventElapsedTime(&e, r.a, r.b));
-    t += e; f += r.flops; n++;
+    t += e; f += r.work; n++;
   }
-  *ms = t; *flops = f; *launches = n;
+  *ms = t; *work = f; *launches = n;
   return SR3D_OK;
 }
 

@@ -88,6 +88,17 @@ int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const 
 bool sr3d_prof_active();
 void sr3d_prof_begin(int id, double flops, hipStream_t st, void** token);
 void sr3d_prof_end(void* token, hipStream_t st);
+// brackets everything launched on `st` during its lifetime (work: FLOPs or bytes, see include/sr3d.h)
+struct SrProfScope {
+  void* tok;
+  hipStream_t st;
+  SrProfScope(int id, double work, hipStream_t s) : tok(nullptr), st(s) {
+    if (sr3d_prof_active()) sr3d_prof_begin(id, work, s, &tok);
+  }
+  ~SrProfScope() { sr3d_prof_end(tok, st); }
+  SrProfScope(const SrProfScope&) = delete;
+  SrProfScope& operator=(const SrProfScope&) = delete;
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

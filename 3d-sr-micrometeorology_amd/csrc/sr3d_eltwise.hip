@@ -230,6 +230,7 @@ int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, v
   SR3D_ALIGN_CHECK(save_s, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_feat, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_gate, "gated_act_bwd");
+  SrProfScope prof(SR3D_PROF_ACT_BWD, 20.0 * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
   hipLaunchKernelGGL(gated_act_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)save_f, (const float*)save_s, (float*)d_feat, (float*)d_gate, n,
                      act);
@@ -242,6 +243,7 @@ int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, void*
   SR3D_ALIGN_CHECK(dy, "lrelu_bwd");
   SR3D_ALIGN_CHECK(y, "lrelu_bwd");
   SR3D_ALIGN_CHECK(dpre, "lrelu_bwd");
+  SrProfScope prof(SR3D_PROF_ACT_BWD, 12.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)y, (float*)dpre, n);
   SR3D_HIP(hipGetLastError());
@@ -255,6 +257,7 @@ int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, i
   SR3D_CHECK((reinterpret_cast<uintptr_t>(dy) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, SR3D_E_ARG,
              "unshuffle_lrelu_bwd: pointers must be 8-byte aligned");
   const long long total = (long long)B * C * 4 * Z * Y * X;
+  SrProfScope prof(SR3D_PROF_ACT_BWD, 12.0 * 2.0 * (double)total, (hipStream_t)stream);
   hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)y, (float*)dpre, B, C, Z, Y, X);
   SR3D_HIP(hipGetLastError());
@@ -268,6 +271,7 @@ int sr3d_upsample_cat(const void* x, const void* b, void* x0, int B, int C, int 
   SR3D_CHECK(Z % scale == 0 && Y % scale == 0 && X % scale == 0, SR3D_E_ARG,
              "upsample_cat: grid (%d,%d,%d) is not a multiple of the scale %d", Z, Y, X, scale);
   const long long total = (long long)B * (C + 1) * Z * Y * X;
+  SrProfScope prof(SR3D_PROF_DATA, 4.0 * ((double)total + (double)total / (C + 1) * (1.0 + C / (double)(scale * scale * scale))), (hipStream_t)stream);
   hipLaunchKernelGGL(upsample_cat_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)x, (const float*)b, (float*)x0, B, C, Z, Y, X, scale);
   SR3D_HIP(hipGetLastError());
@@ -277,6 +281,7 @@ int sr3d_upsample_cat(const void* x, const void* b, void* x0, int B, int C, int 
 int sr3d_avgpool2(const void* in, void* out, int B, int Z, int Y, int X, void* stream) {
   SR3D_CHECK(in && out && B > 0 && Z >= 2 && Y >= 2 && X >= 2, SR3D_E_ARG, "avgpool2: bad argument");
   const long long total = (long long)B * (Z / 2) * (Y / 2) * (X / 2);
+  SrProfScope prof(SR3D_PROF_DATA, 4.0 * 9.0 * (double)total, (hipStream_t)stream);
   hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)in, (float*)out, B, Z, Y, X);
   SR3D_HIP(hipGetLastError());
@@ -286,6 +291,7 @@ int sr3d_avgpool2(const void* in, void* out, int B, int Z, int Y, int X, void* s
 int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* stream) {
   SR3D_CHECK(b && near && B > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG, "near_wall: bad argument");
   const long long total = (long long)B * Z * Y * X;
+  SrProfScope prof(SR3D_PROF_DATA, 8.0 * (double)total, (hipStream_t)stream);
   hipLaunchKernelGGL(near_wall_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)b, (float*)near, B, Z, Y, X);
   SR3D_HIP(hipGetLastError());
@@ -302,6 +308,7 @@ int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   const float step_size = (float)(lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  SrProfScope prof(SR3D_PROF_ADAM, 28.0 * (double)n, (hipStream_t)stream);   // p, m, v read+write, g read
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
                      (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);

@@ -568,6 +568,7 @@ int run_pack(PackParams p, const RowPlan& rp, float* image, hipStream_t st) {
     p.wp = image + (region == 0 ? 0 : region_floats(rp.nblk, p.nchunks, p.ntaps, rp.rt));
     const long long total = (long long)p.nblk * p.nchunks * p.ntaps * p.KC * p.BN;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    SrProfScope prof(SR3D_PROF_PACK, 8.0 * (double)total, st);
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, p);
     SR3D_HIP(hipGetLastError());
   }

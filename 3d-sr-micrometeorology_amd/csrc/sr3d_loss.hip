@@ -295,6 +295,7 @@ int sr3d_l1_fwd_bwd(const void* p, const void* t, long long n, void* loss_out, v
   SR3D_CHECK(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(dLdp)) &
               15) == 0,
              SR3D_E_ARG, "l1_fwd_bwd: pointers must be 16-byte aligned");
+  SrProfScope prof(SR3D_PROF_LOSS, (dLdp ? 12.0 : 8.0) * (double)n, (hipStream_t)stream);
   const int nb = grid_for(n, 8);
   hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, (const float*)p, (const float*)t, n,
                      (float*)workspace, (float*)dLdp, (float)(1.0 / (double)n));
@@ -324,6 +325,8 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
   q.fieldM = ws, q.fieldE = ws + vox;
   q.part = ws + 2 * vox, q.sums = ws + 2 * vox + 4 * kMaxBlocks;
   q.terms = (float*)terms_out, q.dldp = (float*)dLdp;
+  // read p, t (32 B) + b (4 B) per voxel, write dL/dp (16 B)
+  SrProfScope prof(SR3D_PROF_LOSS, (dLdp ? 52.0 : 36.0) * (double)vox, (hipStream_t)stream);
   const int nb = grid_for(vox, 2);
   hipLaunchKernelGGL(mix_pass1_kernel, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, q);
   SR3D_HIP(hipGetLastError());
@@ -354,6 +357,7 @@ int sr3d_mixed_div_grad_l2_bwd(const void* p, const void* t, int B, int Z, int Y
   q.fieldM = ws, q.fieldE = ws + vox;
   q.part = ws + 2 * vox, q.sums = ws + 2 * vox + 4 * kMaxBlocks;
   q.dldp = (float*)dLdp, q.wts = (const float*)term_weights;
+  SrProfScope prof(SR3D_PROF_LOSS, 48.0 * (double)vox, (hipStream_t)stream);   // p, t read, dL/dp written
   hipLaunchKernelGGL(mix_pass2_kernel, dim3(grid_for(vox, 1)), dim3(kThreads), 0, (hipStream_t)stream, q);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

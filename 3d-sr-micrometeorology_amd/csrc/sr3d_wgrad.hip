@@ -692,9 +692,11 @@ extern "C" {
 
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total) {
   if (!d || d->Cin <= 0 || n_total <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
-  if (use_smalln(d, n_total, 1)) return (size_t)smalln_plan(d).S * d->Cin * 108 * 4;
+  // The query does not know into how many dy slices the rows are split, which decides between the small-N kernel
+  // (one slice) and the MFMA kernels: return the largest slab any of the paths the call may take needs.
   const Plan pl = make_plan(d, n_total);
   size_t bytes = (size_t)pl.S * pl.Npad * pl.Jpad * 4;
+  if (use_smalln(d, n_total, 1)) bytes = std::max(bytes, (size_t)smalln_plan(d).S * d->Cin * 108 * 4);
   if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, wino_wgrad_total_ws(d, n_total));
   return bytes;
 }
@@ -786,6 +788,7 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   if (rc) return rc;
   const long long total = (long long)n_total * p.J;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * pl.S * (double)pl.Npad * pl.Jpad, st);   // split-K slabs read once
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)dw, pl.S,
                      n_total, p.J, pl.Npad, pl.Jpad);
   SR3D_HIP(hipGetLastError());
@@ -800,6 +803,7 @@ size_t sr3d_bias_grad_workspace_bytes(int B, int C, long long voxels) {
 int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, void* stream) {
   SR3D_CHECK(dy && db && workspace && B > 0 && C > 0 && voxels > 0, SR3D_E_ARG, "bias_grad: bad argument");
   SR3D_CHECK(C <= 65535, SR3D_E_ARG, "bias_grad: too many channels");
+  SrProfScope prof(SR3D_PROF_BIAS_GRAD, 4.0 * (double)B * C * (double)voxels, (hipStream_t)stream);
   const int ns = bias_splits(voxels);
   hipLaunchKernelGGL(bias_partial_kernel, dim3(ns, C), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                      (float*)workspace, B, C, voxels, ns);

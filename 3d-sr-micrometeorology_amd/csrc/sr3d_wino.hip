@@ -476,6 +476,7 @@ int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1
   for (int i = 0; i < SR3D_MAX_SRC; i++) p.cbeg[i] = cbeg ? cbeg[i] : 0;
   const long long total = (long long)p.nblk * p.nchunks * (WUS / 16);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)rows * K * 27 + (double)p.nblk * p.nchunks * WUS), st);
   hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

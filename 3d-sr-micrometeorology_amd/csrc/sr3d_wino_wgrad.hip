@@ -486,6 +486,7 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   SR3D_HIP(hipGetLastError());
   const long long total = (long long)n_total * c_used * 3;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * g.S * 48.0 * g.Npad * g.Cpad, st);   // split-K slabs read once
   if (g.S > 1) {
     const long long count = (long long)48 * g.Npad * g.Cpad;
     const int sblocks = (int)std::min<long long>((count + 255) / 256, 16384);

@@ -22,11 +22,12 @@ def get_all_new_lr_data_dir_paths(root_dir: pathlib.Path, dir_name: str = "10") 
 
 def _ordered_split(items, test_fraction: float):
     """sklearn.model_selection.train_test_split(shuffle=False) for a float test size:
-    n_test = ceil(f * n), n_train = floor((1 - f) * n)"""
+    n_test = ceil(f * n) and the train part is the complement, n_train = n - n_test (sklearn's
+    _validate_shuffle_split; floor((1 - f) * n) differs from it for some (f, n), e.g. f = 0.3, n = 90)"""
     n = len(items)
     n_test = int(math.ceil(test_fraction * n))
-    n_train = int(math.floor((1.0 - test_fraction) * n))
-    return items[:n_train], items[n_train:n_train + n_test]
+    n_train = n - n_test
+    return items[:n_train], items[n_train:]
 
 
 def split_into_train_valid_test_dirs(all_data_dirs, train_valid_test_ratios):

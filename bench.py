@@ -6,14 +6,19 @@
 One "step" = forward + loss + zero_grad + backward (+ gradient all-reduce for
 N > 1) + Adam of the reference's UNetSR (default.yml widths, 65.47 M parameters)
 on one synthetic batch, i.e. the body of reference
-pytorch/src/optim_helper.py:156-178.  Workload at every N = BASELINE.json
-configs[1]: LR (1,4,20,80,80) -> HR (1,4,80,320,320) per GPU, fp32, L1 loss
-(weak scaling: per-GPU batch fixed at 1).  ``--loss mixed`` switches to the
-physics-guided loss of configs[2]; ``--batch`` changes the per-GPU batch.
+pytorch/src/optim_helper.py:156-178.
+
+Workload (HR 80x320x320 from LR 20x80x80, fp32, weak scaling):
+  N = 1 : BASELINE.json configs[1] -- batch 1, L1 loss.  A short second measurement of configs[2] (batch 4, the
+          physics-guided loss: the per-GPU work of configs[3]) is attached as "config2_batch4_mixed".
+  N > 1 : BASELINE.json configs[3] -- batch 4 per GPU (global 4 N), physics-guided loss, gradient all-reduce over
+          RCCL.  A short second measurement of configs[1]'s per-GPU work (batch 1, L1) is attached as
+          "config1_batch1_l1", so that per-GPU throughput can be compared with the N = 1 line like for like.
+``--batch`` / ``--loss`` override the primary workload.
 
 Prints ONE JSON line (rank 0) with the metric, the roofline figure of the
-dominant kernel measured live with HIP events, and a CPU baseline (the oracle,
-timed on this host's cores on a bounded sample).
+dominant kernel measured live with HIP events, GB/s of the HBM-bound kernel families,
+and a CPU baseline (the oracle, timed on this host's cores on a bounded sample).
 """
 import argparse
 import ctypes as C
@@ -34,7 +39,11 @@ FLOP_PER_VOXEL = 8_486_693
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # HBM traffic of the dominant kernel family per launch, from separate rocprofv3 --pmc passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass; FETCH_SIZE doubled as the guide prescribes for gfx950)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")]
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+BYTES_PER_VOXEL = 11_586       # compulsory fwd+bwd activation traffic per HR voxel, fp32
+FAMILIES = {"igemm_s1": 0, "igemm_s2": 1, "igemm_bwd_s2": 2, "wgrad": 3, "loss": 4, "act_bwd": 5, "bias_grad": 6,
+            "adam": 7, "data": 8, "pack_reduce": 9}
 
 DEFAULT_CONFIG = {
     "data": {"stds": [8.40, 14.40, 21.60, 7.00]},
@@ -73,6 +82,16 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """the CPU oracle (oracle/ref_cpu.py: stock ATen conv3d etc., pinned to the reference by
     tests/golden) on the reference's own training crop size, timed on this host's cores"""
@@ -94,10 +113,79 @@ def cpu_baseline(cfg, budget_s=20.0):
             break
     sec = sum(times) / len(times)
     vox = hr[0] * hr[1] * hr[2]
-    return {"value": vox / sec, "unit": "HR voxels/s", "cores": cores, "kind": "port",
+    return {"value": vox / sec, "unit": "HR voxels/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{len(times)} full training steps (fwd+loss+bwd+Adam, same model and loss) of the CPU oracle "
                       f"on one HR {hr[0]}x{hr[1]}x{hr[2]} crop (LR 8x16x16), {sec:.2f} s/step; the 80x320x320 "
                       f"volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
+
+
+def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, steps, warmup):
+    """W untimed + K timed training steps of one workload; returns wall time (max over ranks) and the per-family
+    HIP-event totals of the timed steps"""
+    cfg = make_config(loss_name)
+    scale = 2 ** cfg["model"]["num_x2upsample"]
+    hr = tuple(v * scale for v in lr_grid)
+    torch.manual_seed(42)
+    model = sr3d_amd.make_model(cfg).to(dev)
+    loss_fn = sr3d_amd.make_loss(cfg)
+    opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"])
+    reducer = None
+    if use_dist:
+        reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
+        reducer.broadcast_parameters(opt.flat_param)
+    x, b, y = synthetic_batch(batch, hr, scale, 1234 + rank, dev)
+
+    def step():
+        pred = model(x, b)
+        loss = loss_fn(pred, y, b)
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            opt.grad_scale = reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    L.lib.sr3d_profile_enable(1)        # creates its event pool here, outside the timed region
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    last_loss = float(loss.detach())
+
+    prof = {}
+    for name, kid in list(FAMILIES.items()) + [("dropped", 99)]:
+        ms, work, n = C.c_double(), C.c_double(), C.c_longlong()
+        L.check(L.lib.sr3d_profile_read(kid, C.byref(ms), C.byref(work), C.byref(n)), "sr3d_profile_read")
+        prof[name] = {"ms": ms.value, "work": work.value, "launches": n.value}
+    L.lib.sr3d_profile_enable(0)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if reducer is not None:
+        reducer.remove_hooks()
+    del model, opt, reducer, x, b, y, loss
+    torch.cuda.empty_cache()
+    return {"elapsed": float(t.item()), "prof": prof, "loss": last_loss, "hr": hr, "cfg": cfg,
+            "voxels_per_step": world * batch * hr[0] * hr[1] * hr[2]}
+
+
+def workload_name(lr_grid, hr, batch, loss_name, world):
+    cfg_id = {("l1", False): 1, ("mixed", False): 2, ("mixed", True): 3}.get((loss_name, world > 1))
+    tag = f" (BASELINE configs[{cfg_id}])" if cfg_id is not None and (batch == (1 if loss_name == "l1" else 4)) else ""
+    return (f"LR {lr_grid[0]}x{lr_grid[1]}x{lr_grid[2]} -> 4x SR HR {hr[0]}x{hr[1]}x{hr[2]}, batch {batch}/GPU, fp32, "
+            f"UNetSR default.yml widths (65.47M params), {'L1' if loss_name == 'l1' else 'MixedDivergenceGradientL2'} "
+            f"loss, fwd+loss+bwd{'+RCCL grad all-reduce' if world > 1 else ''}+Adam{tag}")
 
 
 def main():
@@ -105,10 +193,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="per-GPU batch")
-    ap.add_argument("--loss", choices=["l1", "mixed"], default="l1")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 1 for N = 1, 4 for N > 1)")
+    ap.add_argument("--loss", choices=["l1", "mixed"], default=None, help="default: l1 for N = 1, mixed for N > 1")
     ap.add_argument("--lr-grid", type=int, nargs=3, default=[20, 80, 80], metavar=("Z", "Y", "X"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short second workload")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and the bucketed all-reduce even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
@@ -132,77 +221,40 @@ def main():
     import sr3d_amd
     from sr3d_amd import _lib as L
 
-    cfg = make_config(args.loss)
-    scale = 2 ** cfg["model"]["num_x2upsample"]
-    hr = tuple(v * scale for v in args.lr_grid)
-    torch.manual_seed(42)
-    model = sr3d_amd.make_model(cfg).to(dev)
-    loss_fn = sr3d_amd.make_loss(cfg)
-    opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"])
-    reducer = None
-    if use_dist:
-        reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
-        reducer.broadcast_parameters(opt.flat_param)
-    x, b, y = synthetic_batch(args.batch, hr, scale, 1234 + rank, dev)
-
-    def step():
-        pred = model(x, b)
-        loss = loss_fn(pred, y, b)
-        opt.zero_grad()
-        loss.backward()
-        if reducer is not None:
-            opt.grad_scale = reducer.finish()
-        opt.step()
-        return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    L.lib.sr3d_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    last_loss = float(loss.detach())
-
-    # per-kernel HIP-event times collected during the timed steps
-    prof = {}
-    for name, kid in (("igemm_s1", 0), ("igemm_s2", 1), ("igemm_bwd_s2", 2), ("wgrad", 3)):
-        ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
-        L.check(L.lib.sr3d_profile_read(kid, C.byref(ms), C.byref(fl), C.byref(n)), "sr3d_profile_read")
-        prof[name] = {"ms": ms.value, "flops": fl.value, "launches": n.value}
-    L.lib.sr3d_profile_enable(0)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    batch = args.batch if args.batch is not None else (1 if world == 1 else 4)
+    loss_name = args.loss if args.loss is not None else ("l1" if world == 1 else "mixed")
+    m = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, args.steps, args.warmup)
+    second = None
+    if not args.no_secondary and args.batch is None and args.loss is None:
+        sb, sl = (4, "mixed") if world == 1 else (1, "l1")
+        second = measure(sr3d_amd, L, dev, rank, world, use_dist, sb, sl, args.lr_grid, min(args.steps, 3), 1)
+        second["batch"], second["loss_name"] = sb, sl
 
     if rank == 0:
-        vox_per_step = world * args.batch * hr[0] * hr[1] * hr[2]
-        value = vox_per_step * args.steps / elapsed
+        elapsed, prof, hr = m["elapsed"], m["prof"], m["hr"]
+        value = m["voxels_per_step"] * args.steps / elapsed
         dom = prof["igemm_s1"]
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        algo = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         wino = os.environ.get("SR3D_WINOGRAD", "1") != "0"
+        executed = algo / (2.25 if wino else 1.0)
         traffic = None
-        if os.path.exists(TRAFFIC_JSON) and args.batch == 1 and args.loss == "l1" and wino:
-            t = json.load(open(TRAFFIC_JSON)).get("igemm_s1")
+        tj = next((f for f in TRAFFIC_JSONS if os.path.exists(f)), None)
+        if tj and batch == 1 and loss_name == "l1" and wino:
+            t = json.load(open(tj)).get("igemm_s1")
             if t:
                 traffic = {"hbm_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"] + t["write_bytes_per_launch"],
                            "fetch_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"],
                            "write_bytes_per_launch": t["write_bytes_per_launch"],
-                           "kernel_launches_per_step": t["launches_profiled"] / 2,   # a conv call may issue 2 launches
-                           "source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-        per_kernel = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
-                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
-                      for k, v in prof.items()}
+                           "kernel_launches_profiled": t["launches_profiled"],
+                           "source": os.path.relpath(tj, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        conv = {k: {"ms_per_step": prof[k]["ms"] / args.steps, "launches_per_step": prof[k]["launches"] / args.steps,
+                    "algorithmic_tflops": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e12 if prof[k]["ms"] > 0 else 0.0)}
+                for k in ("igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")}
+        hbm = {k: {"ms_per_step": prof[k]["ms"] / args.steps, "launches_per_step": prof[k]["launches"] / args.steps,
+                   "gbytes_per_s": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9 if prof[k]["ms"] > 0 else 0.0),
+                   "frac_of_hbm_peak": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                        if prof[k]["ms"] > 0 else 0.0)}
+               for k in ("loss", "act_bwd", "bias_grad", "adam", "data", "pack_reduce")}
         out = {
             "metric": "training voxels/sec (fwd+bwd+loss) on 4x 3D SR",
             "value": value,
@@ -216,31 +268,43 @@ def main():
             "vs_baseline": None,
             "dtype": "fp32",
             "data": "synthetic",
-            "config": {"workload": f"LR {args.lr_grid[0]}x{args.lr_grid[1]}x{args.lr_grid[2]} -> 4x SR HR "
-                                   f"{hr[0]}x{hr[1]}x{hr[2]}, batch {args.batch}/GPU, fp32, UNetSR default.yml widths "
-                                   f"(65.47M params), {'L1' if args.loss == 'l1' else 'MixedDivergenceGradientL2'} "
-                                   f"loss, fwd+loss+bwd+Adam (BASELINE configs[{1 if args.loss == 'l1' else 2}])",
-                       "global_batch": world * args.batch,
+            "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world),
+                       "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": executed, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": executed / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
                                    "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)",
-                         "note": "achieved = ALGORITHMIC FLOPs of the 3x3x3 convolution (2*27*Cin*Cout per output voxel) / "
-                                 "kernel time, so frac can exceed 1: the Winograd kernel issues 2.25x fewer MFMA FLOPs "
-                                 "than the algorithm counts.  executed_tflops / frac_executed price the MFMAs the "
-                                 "kernel really issues against the same fp32 MFMA peak (all arithmetic is fp32)",
-                         "executed_tflops": ach / (2.25 if wino else 1.0),
-                         "frac_executed": ach / (2.25 if wino else 1.0) / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "achieved = fp32 MFMA FLOPs the kernel EXECUTES per second = algorithmic FLOPs of the "
+                                 "3x3x3 convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d)) / 2.25 (Winograd "
+                                 "F(2x2,3x3) in (y,x) needs 48 instead of 108 products per 2x2x1 outputs) / kernel time "
+                                 "from HIP events; frac = matrix-pipe utilisation against the fp32 MFMA peak",
+                         "algorithmic_tflops": algo,
                          "launches_per_step": dom["launches"] / args.steps,
                          "kernel_ms_per_step": dom["ms"] / args.steps},
-            "step_tflops": FLOP_PER_VOXEL * value / 1e12,
-            "step_mfma_frac": FLOP_PER_VOXEL * value / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
-            "kernels": per_kernel,
-            "loss": last_loss,
+            "hbm_frac": value / (world * HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL),
+            "hbm_note": f"voxels/s against the HBM-only ceiling {HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL / 1e6:.0f} M voxels/s/GPU "
+                        f"(8 TB/s / {BYTES_PER_VOXEL} B of compulsory activation traffic per voxel); the step is "
+                        "contraction-bound (AI ~ 730 FLOP/B), so this fraction cannot exceed ~1/16 at fp32-MFMA peak "
+                        "even with Winograd",
+            "step_algorithmic_tflops": FLOP_PER_VOXEL * value / 1e12,
+            "conv_kernels": conv,
+            "hbm_bound_kernels": hbm,
+            "profile_records_dropped": prof["dropped"]["launches"],
+            "loss": m["loss"],
         }
+        if second is not None:
+            key = "config2_batch4_mixed" if world == 1 else "config1_batch1_l1"
+            sv = second["voxels_per_step"] * min(args.steps, 3) / second["elapsed"]
+            sp = second["prof"]
+            out[key] = {"workload": workload_name(args.lr_grid, second["hr"], second["batch"], second["loss_name"], world),
+                        "value": sv, "unit": "HR voxels/s", "steps": min(args.steps, 3), "warmup": 1,
+                        "ms_per_step": second["elapsed"] / min(args.steps, 3) * 1e3, "loss": second["loss"],
+                        "loss_kernels_ms_per_step": sp["loss"]["ms"] / min(args.steps, 3),
+                        "loss_kernels_gbytes_per_s": (sp["loss"]["work"] / (sp["loss"]["ms"] * 1e-3) / 1e9
+                                                      if sp["loss"]["ms"] > 0 else 0.0)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(m["cfg"])
         print(json.dumps(out), flush=True)
 
     if use_dist:

@@ -155,18 +155,27 @@ int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
 
 /* ---- measurement hook (bench.py's roofline leg; no reference counterpart) --------
- * When enabled, every launch of the conv kernels is bracketed by two HIP events on the
- * stream it is launched on.  sr3d_profile_read() returns, for one kernel family, the
- * summed event time, the summed ALGORITHMIC FLOPs (2 * 27 * Cin * Cout * output voxels,
- * padding not counted) and the number of launches since the last enable. */
+ * When enabled, every launch of the kernels below is bracketed by two HIP events (taken from a pool that
+ * sr3d_profile_enable(1) creates, so nothing is allocated inside a timed region) on the stream it is launched on.
+ * sr3d_profile_read() returns, for one kernel family, the summed event time, the summed ALGORITHMIC work and the
+ * number of launches since the last enable.  Work = FLOPs (2 * 27 * Cin * Cout * output voxels, padding not counted)
+ * for the convolution families, BYTES (compulsory reads + writes of the operation) for the HBM-bound families. */
 enum {
-  SR3D_PROF_IGEMM_S1 = 0,     /* stride-1 conv forward and stride-1 input gradient */
-  SR3D_PROF_IGEMM_S2 = 1,     /* stride-2 conv forward */
-  SR3D_PROF_IGEMM_BWD_S2 = 2, /* stride-2 input gradient (8 parity classes) */
-  SR3D_PROF_WGRAD = 3         /* weight gradient (main kernel, without the slab reduce) */
+  SR3D_PROF_IGEMM_S1 = 0,     /* stride-1 conv forward and stride-1 input gradient           [FLOP] */
+  SR3D_PROF_IGEMM_S2 = 1,     /* stride-2 conv forward                                       [FLOP] */
+  SR3D_PROF_IGEMM_BWD_S2 = 2, /* stride-2 input gradient (8 parity classes)                  [FLOP] */
+  SR3D_PROF_WGRAD = 3,        /* weight gradient (main kernel, without the slab reduce)      [FLOP] */
+  SR3D_PROF_LOSS = 4,         /* L1 / mixed loss: value + dL/dp (all passes)                 [byte] */
+  SR3D_PROF_ACT_BWD = 5,      /* gated / LeakyReLU / unshuffle activation backward           [byte] */
+  SR3D_PROF_BIAS_GRAD = 6,    /* bias gradient (both stages)                                 [byte] */
+  SR3D_PROF_ADAM = 7,         /* fused Adam                                                  [byte] */
+  SR3D_PROF_DATA = 8,         /* upsample+concat, mask pyramid, near-wall mask               [byte] */
+  SR3D_PROF_PACK = 9,         /* weight packing / transforms and split-K reductions          [byte] */
+  SR3D_PROF_FAMILIES = 10,
+  SR3D_PROF_DROPPED = 99      /* launches: records lost because the event pool was exhausted */
 };
 int sr3d_profile_enable(int on);
-int sr3d_profile_read(int kernel_id, double* ms, double* flops, long long* launches);
+int sr3d_profile_read(int kernel_id, double* ms, double* work, long long* launches);
 
 #ifdef __cplusplus
 }

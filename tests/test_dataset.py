@@ -2,6 +2,8 @@
 reference's own DatasetWithoutAligningResolution on the same synthetic files.  CPU only."""
 import os
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -53,3 +55,18 @@ def test_dataloaders_yield_batches_the_loops_expect(tree):
     Xs, bs, ys = next(iter(loaders["train"]))
     assert tuple(Xs.shape) == (2, 4, 2, 2, 3) and tuple(bs.shape) == (2, 8, 8, 12) and tuple(ys.shape) == (2, 4, 8, 8, 12)
     assert samplers == {}
+
+
+def test_ordered_split_matches_sklearn_for_every_fraction():
+    """the engine's chronological split == sklearn.model_selection.train_test_split(shuffle=False), which the
+    reference calls (dataloader.py:88-104), for fractions / lengths where floor and ceil rounding disagree"""
+    from sklearn.model_selection import train_test_split
+
+    from sr3d_amd.src.dataloader import _ordered_split
+    for n in list(range(2, 60)) + [90, 97, 365, 1000]:
+        items = list(range(n))
+        for f in (0.1, 0.2, 0.25, 0.3, 1 / 3, 0.5, 0.7):
+            if not 0 < math.ceil(f * n) < n:
+                continue
+            a, b = train_test_split(items, test_size=f, shuffle=False)
+            assert (a, b) == tuple(_ordered_split(items, f)), (n, f)

@@ -268,3 +268,23 @@ def test_alternative_kernel_paths_in_subprocess(env):
                         "conv_wrappers or split_sources or upblock or full_model or odd_shapes or fullwidth"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_gated_conv_with_two_output_channels(eng):
+    """n_dy = 2 with n_total <= 4: the weight-gradient workspace query must cover the path the call really takes"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(1, 6, 8, 16, 32, generator=g) - 0.5).requires_grad_(True)
+    wf = (torch.randn(2, 6, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    wg = (torch.randn(2, 6, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    bg = (torch.randn(2, generator=g) * 0.1).requires_grad_(True)
+    ref = torch.sigmoid(F.conv3d(x, wg, bg, padding=1)) * F.conv3d(x, wf, None, padding=1)
+    gy = torch.rand(ref.shape, generator=g) - 0.5
+    ref.backward(gy)
+    xd, wfd, wgd, bgd = (t.detach().to(DEV).requires_grad_(True) for t in (x, wf, wg, bg))
+    y = eng.ops.gated_conv3d_act([xd], wfd, wgd, None, bgd, act=None)
+    assert relerr(y, ref) < TOL
+    y.backward(gy.to(DEV))
+    assert relerr(xd.grad, x.grad) < TOL
+    assert relerr(wfd.grad, wf.grad) < TOL_G and relerr(wgd.grad, wg.grad) < TOL_G
+    assert relerr(bgd.grad, bg.grad) < TOL_G
