@@ -17,6 +17,11 @@ LIB_PATH = os.path.join(_HERE, "libsr3d.so")
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED = 0, 1, 2, 3
 ACT_CODE = {None: ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU}
+# indices into the output of sr3d_eval_metrics (include/sr3d.h: SR3D_EVAL_*)
+EVAL_INDEX = {"L1": 0, "L2": 1, "MaskedL1": 2, "MaskedL2": 3, "MaskedL1NearWall": 4, "MaskedL2NearWall": 5,
+              "ResidualContinuity": 6, "ResidualContinuityTarget": 7, "AbsDiffTemperature": 8, "DiffVelocityNorm": 9,
+              "AbsDiffTemperatureLev": 10, "DiffVelocityNormLev": 11, "AbsDiffDivergence": 12, "DiffOmegaNorm": 13}
+EVAL_COUNT = 14
 
 
 class Slice(C.Structure):
@@ -54,6 +59,8 @@ SYMBOLS = {
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_bwd": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
+    "sr3d_eval_metrics_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "sr3d_eval_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _I, _P, _P, _P]),
     "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),
     "sr3d_profile_enable": (_I, [_I]),
     "sr3d_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

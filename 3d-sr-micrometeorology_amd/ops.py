@@ -301,6 +301,43 @@ class MixedLossFn(torch.autograd.Function):
         return dp, None, None, None, None, None, None
 
 
+# ---------------------------------------------------------------- evaluation metrics
+_eval_cache: dict = {"key": None, "stds": None, "out": None}
+
+
+def _eval_key(p, t, b, delta, lev):
+    return (p.data_ptr(), p._version, t.data_ptr(), t._version, b.data_ptr(), b._version, tuple(p.shape), float(delta),
+            int(lev), torch.cuda.current_stream().cuda_stream)
+
+
+def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequence[Optional[float]],
+                 delta: float = 5.0, lev: int = 0) -> torch.Tensor:
+    """All evaluation metrics of the reference's test pass from ONE fused kernel (include/sr3d.h: sr3d_eval_metrics);
+    returns the SR3D_EVAL_COUNT-vector on the device (index with ``_lib.EVAL_INDEX``).
+
+    ``stds`` = (std_T, std_u, std_v, std_w); an entry may be None when the caller does not depend on it.  The result
+    of the last launch is kept: the reference calls its ten metric modules one after the other on the same
+    (prediction, target, mask), and every call after the first is a cache hit as long as the scales it needs agree
+    with the ones the launch used (``optim_helper.evaluate`` makes the first call with the union of all scales)."""
+    p, t, b = p.detach().contiguous(), t.detach().contiguous(), b.detach().contiguous()
+    B, c, Z, Y, X = p.shape
+    if c != 4 or t.shape != p.shape or tuple(b.shape) != (B, 1, Z, Y, X):
+        raise ValueError("eval_metrics expects p, t: (B,4,Z,Y,X) and masks: (B,1,Z,Y,X)")
+    key = _eval_key(p, t, b, delta, lev)
+    want = [None if v is None else float(v) for v in stds]
+    if _eval_cache["key"] == key and all(w is None or w == h for w, h in zip(want, _eval_cache["stds"])):
+        return _eval_cache["out"]
+    used = [1.0 if w is None else w for w in want]
+    ws = torch.empty(L.lib.sr3d_eval_metrics_workspace_bytes(B, Z, Y, X) // 4, dtype=torch.float32, device=p.device)
+    out = _empty((L.EVAL_COUNT,), p)
+    sc = (C.c_float * 4)(*used)
+    L.check(L.lib.sr3d_eval_metrics(L.dev_ptr(p), L.dev_ptr(t), L.dev_ptr(b), B, Z, Y, X, sc, float(delta), int(lev),
+                                    L.dev_ptr(out), L.dev_ptr(ws), L.stream_ptr()), "sr3d_eval_metrics")
+    # entries a caller left open are NOT remembered as 1.0: a later caller that needs them must relaunch
+    _eval_cache.update(key=key, stds=[w if w is not None else float("nan") for w in want], out=out)
+    return out
+
+
 # ---------------------------------------------------------------- optimizer
 def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float,
                beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0) -> None:

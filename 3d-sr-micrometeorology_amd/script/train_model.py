@@ -61,8 +61,7 @@ class _Both:
 def train_and_validate(rank: int, world_size: int, config: dict, weight_path: str, learning_history_path: str,
                        data_root: str, port: int):
     import sr3d_amd
-    from sr3d_amd.src.dataloader import (get_all_new_lr_data_dir_paths, make_dataloaders,
-                                         split_into_train_valid_test_dirs)
+    from sr3d_amd.src.dataloader import data_dirs_of_config, make_dataloaders, split_into_train_valid_test_dirs
     from sr3d_amd.src.gradnorm import GradNorm
     from sr3d_amd.src.optim_helper import test_ddp, train_ddp
     from sr3d_amd.src.utils import set_seeds
@@ -77,10 +76,7 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
     set_seeds(config["train"]["seed"])
     use_grad_norm = "grad_norm" in config["train"]
 
-    names = config["data"]["data_dir_names"]
-    if names not in (["10"], ["20"]):
-        raise Exception(f"data_dir_names == {names} are not supported.")
-    all_data_dirs = get_all_new_lr_data_dir_paths(pathlib.Path(data_root), dir_name=names[0])
+    all_data_dirs = data_dirs_of_config(config, pathlib.Path(data_root))
     split = split_into_train_valid_test_dirs(all_data_dirs, config["data"]["train_valid_test_ratios"])
     dataloaders, samplers = make_dataloaders(
         rank=rank, world_size=world_size, data_dirs=split, hr_3d_build_path=all_data_dirs[0].parent / "hr_is_in_build.npy",
@@ -175,23 +171,30 @@ def main():
                                            _free_port()), nprocs=args.world_size, join=True)
         logger.info(f"Total elapsed time = {time.time() - t0} sec")
 
-        # final evaluation on the test split (train_model.py:351-390), rank-0 process, cuda:0
+        # final evaluation on the test split (train_model.py:351-390): whole domain, the reference's ten metrics
         import sr3d_amd
-        from sr3d_amd.src.dataloader import (get_all_new_lr_data_dir_paths, make_dataloaders,
-                                             split_into_train_valid_test_dirs)
+        from sr3d_amd.src import loss_maker as lm
+        from sr3d_amd.src.dataloader import make_evaluation_dataloader_without_random_cropping
         from sr3d_amd.src.optim_helper import evaluate
         model = sr3d_amd.make_model(config).to("cuda:0")
-        model.load_state_dict(torch.load(weight_path))
-        dirs = get_all_new_lr_data_dir_paths(pathlib.Path(args.data_root), dir_name=config["data"]["data_dir_names"][0])
-        loaders, _ = make_dataloaders(split_into_train_valid_test_dirs(dirs, config["data"]["train_valid_test_ratios"]),
-                                      dirs[0].parent / "hr_is_in_build.npy",
-                                      hr_org_size=tuple(config["data"]["hr_org_size"]),
-                                      hr_crop_size=tuple(config["data"]["hr_crop_size"]), batch_size=1, num_workers=0,
-                                      means=config["data"]["means"], stds=config["data"]["stds"],
-                                      nan_value=config["data"]["nan_value"], seed=config["data"]["seed"])
-        l1_cfg = {**config, "train": {**config["train"], "loss": {"name": "L1"}}}
-        results = evaluate(dataloader=loaders["test"], model=model, device="cuda:0",
-                           loss_fns={"L1": sr3d_amd.make_loss(l1_cfg), config["train"]["loss"]["name"]: sr3d_amd.make_loss(config)})
+        model.load_state_dict(torch.load(weight_path, map_location="cuda:0"))
+        model.eval()
+        test_loader = make_evaluation_dataloader_without_random_cropping(config, pathlib.Path(args.data_root),
+                                                                         batch_size=1, num_workers=0)
+        stds = config["data"]["stds"]
+        loss_fns = {
+            "L1": lm.MyL1Loss(),
+            "MaskedL1": lm.MaskedL1Loss(),
+            "MaskedL1NearWall": lm.MaskedL1LossNearWall(),
+            "ResidualContinuityEq": lm.ResidualContinuity(stds[1:]),
+            "AbsDiffTemperature": lm.AbsDiffTemperature(stds[0]),
+            "DiffVelocityNorm": lm.DiffVelocityVectorNorm(stds[1:]),
+            "AbsDiffTemperatureLevZero": lm.AbsDiffTemperature(stds[0], lev=0),
+            "DiffVelocityNormLevZero": lm.DiffVelocityVectorNorm(stds[1:], lev=0),
+            "AbsDiffDivergence": lm.AbsDiffDivergence(stds[1:]),
+            "DiffOmegaVectorNorm": lm.DiffOmegaVectorNorm(stds[1:]),
+        }
+        results = evaluate(dataloader=test_loader, model=model, loss_fns=loss_fns, device="cuda:0")
         for k, v in results.items():
             logger.info(f"{k}: {v.avg:.8f}")
             if mlflow is not None:

@@ -20,6 +20,31 @@ def get_all_new_lr_data_dir_paths(root_dir: pathlib.Path, dir_name: str = "10") 
     return [pathlib.Path(p) for p in sorted(glob.glob(str(pathlib.Path(root_dir) / dir_name / "*"))) if os.path.isdir(p)]
 
 
+def get_all_data_dir_paths(root_dir: pathlib.Path) -> typing.List[pathlib.Path]:
+    """dataloader.py:20-60: the three hourly directory sets 03 / 04 / 05, one entry per date and set, ordered
+    04, 03, 05 within a date (the chronological order of the simulations)"""
+    root_dir = pathlib.Path(root_dir)
+    per_set = {n: [p for p in sorted(glob.glob(str(root_dir / n / "*"))) if os.path.isdir(p)] for n in ("03", "04", "05")}
+    assert len(per_set["03"]) == len(per_set["04"]) == len(per_set["05"])
+    out = []
+    for d04, d03, d05 in zip(per_set["04"], per_set["03"], per_set["05"]):
+        assert os.path.basename(d04) == os.path.basename(d03) == os.path.basename(d05)   # same date
+        out += [pathlib.Path(d04), pathlib.Path(d03), pathlib.Path(d05)]
+    return out
+
+
+def data_dirs_of_config(config: dict, data_dir_root: pathlib.Path) -> typing.List[pathlib.Path]:
+    """the directory sets a config names (train_model.py:134-147, dataloader.py:203-216)"""
+    names = config["data"]["data_dir_names"]
+    if names == ["03", "04", "05"]:
+        return get_all_data_dir_paths(data_dir_root)
+    if names == ["10"]:
+        return get_all_new_lr_data_dir_paths(data_dir_root)
+    if names == ["20"]:
+        return get_all_new_lr_data_dir_paths(data_dir_root, dir_name="20")
+    raise Exception(f"Data dirs {names} are not supported.")
+
+
 def _ordered_split(items, test_fraction: float):
     """sklearn.model_selection.train_test_split(shuffle=False) for a float test size:
     n_test = ceil(f * n) and the train part is the complement, n_train = n - n_test (sklearn's
@@ -65,3 +90,24 @@ def make_dataloaders(data_dirs, hr_3d_build_path, means=[0.0] * 4, stds=[1.0] * 
         if rank in (None, 0):
             logger.info(f"{kind}: dataset size = {len(dataset)}, batch num = {len(loaders[kind])}")
     return loaders, samplers
+
+
+def make_evaluation_dataloader_without_random_cropping(config: dict, data_dir_root: pathlib.Path, batch_size: int = 1,
+                                                       num_workers: int = 2, max_height_index: int = 32):
+    """dataloader.py:195-246: the test split, whole domain (no crop), HR not clipped, in file order.  Every
+    ``config['data']`` key that shapes a sample is forwarded (lr_scaling, max_discarded_lr_z_index, scale_factor,
+    datasizes['test']), so a model trained on LR with the lowest levels discarded is evaluated on the same kind of
+    input."""
+    data_dir_root = pathlib.Path(data_dir_root)
+    all_data_dirs = data_dirs_of_config(config, data_dir_root)
+    test_dirs = split_into_train_valid_test_dirs(all_data_dirs, config["data"]["train_valid_test_ratios"])["test"]
+    d = config["data"]
+    dataset = DatasetWithoutAligningResolution(
+        data_dirs=test_dirs, hr_3d_build_path=all_data_dirs[0].parent / "hr_is_in_build.npy", means=d["means"],
+        stds=d["stds"], nan_value=d["nan_value"], hr_org_size=tuple(d["hr_org_size"]),
+        hr_crop_size=tuple(d["hr_crop_size"]), use_cropping=False, use_clipping=False,
+        datasize=d["datasizes"]["test"], seed=d["seed"], lr_scaling=d.get("lr_scaling", None),
+        max_height_index=max_height_index, max_discarded_lr_z_index=d.get("max_discarded_lr_z_index", None),
+        scale_factor=d.get("scale_factor", 4))
+    return DataLoader(dataset, batch_size=batch_size, drop_last=False, shuffle=False, pin_memory=False,
+                      num_workers=num_workers)

@@ -1,8 +1,10 @@
-"""Training losses with the reference's factory and module interface
-(pytorch/src/loss_maker.py:19-54, 194-213, 358-450), evaluated by the fused HIP
-loss kernels (value and dL/dprediction in one launch sequence)."""
+"""Training losses and evaluation metrics with the reference's factory and module interface
+(pytorch/src/loss_maker.py:19-54, 194-213, 358-450 and 453-745).  Training losses run the fused HIP loss kernels
+(value and dL/dprediction in one launch sequence); the evaluation metrics all read their value from ONE fused
+pass over (prediction, target, mask) (``ops.eval_metrics``), however many of them are evaluated on a batch."""
 from copy import deepcopy
 from logging import getLogger
+import typing
 from typing import List
 
 import numpy as np
@@ -44,6 +46,10 @@ def calc_mask_near_build_wall(building: torch.Tensor, num_filter_applications: i
 
 class MyL1Loss(nn.Module):
     def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor = None):
+        if masks is not None and not (torch.is_grad_enabled() and predicts.requires_grad) and predicts.dim() == 5 \
+                and predicts.shape[1] == 4:
+            # evaluation: the value comes out of the fused metrics pass (shared with the other metrics of the batch)
+            return ops.eval_metrics(predicts, targets, masks, (None,) * 4)[0]
         return ops.L1LossFn.apply(predicts, targets)
 
 
@@ -84,3 +90,166 @@ class MixedDivergenceGradientL2Loss(nn.Module):
 
     def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
         return self._terms(predicts, targets, masks)[3]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evaluation metrics (no gradient): pytorch/src/loss_maker.py:453-745, used by script/train_model.py:366-390 and
+# the evaluation notebooks.  Constructor arguments and forward(predicts, targets, masks) as in the reference.
+from .._lib import EVAL_INDEX  # noqa: E402
+
+
+class _FusedMetric(nn.Module):
+    """one entry of the fused evaluation pass"""
+    entry: str = ""
+
+    def _stds(self):           # (std_T, std_u, std_v, std_w) as far as this metric depends on them
+        return (None, None, None, None)
+
+    def _lev(self) -> int:
+        return 0
+
+    delta_meter = 5.0
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        out = ops.eval_metrics(predicts, targets, masks, self._stds(), self.delta_meter, self._lev())
+        return out[EVAL_INDEX[self.entry]]
+
+
+def _check_eps(eps: float):
+    if eps != 1e-30:
+        raise NotImplementedError("the fused evaluation kernel implements the reference's default eps = 1e-30")
+
+
+class MaskedL1Loss(_FusedMetric):
+    entry = "MaskedL1"
+
+    def __init__(self, eps: float = 1e-30):
+        super().__init__()
+        _check_eps(eps)
+        self.eps = eps
+
+
+class MaskedL2Loss(MaskedL1Loss):
+    entry = "MaskedL2"
+
+
+class MaskedL1LossNearWall(_FusedMetric):
+    entry = "MaskedL1NearWall"
+
+    def __init__(self, eps: float = 1e-30, num_filter_applications: int = 1):
+        super().__init__()
+        _check_eps(eps)
+        if num_filter_applications != 1:
+            raise NotImplementedError("num_filter_applications != 1")
+        self.eps, self.num_filter_applications = eps, num_filter_applications
+
+
+class MaskedL2LossNearWall(MaskedL1LossNearWall):
+    entry = "MaskedL2NearWall"
+
+
+class _VelocityMetric(_FusedMetric):
+    def __init__(self, scales: List[float], delta_meter: float = 5.0):
+        super().__init__()
+        assert len(scales) == 3
+        self.scales = deepcopy(scales)
+        self.delta_meter = delta_meter
+
+    def _stds(self):
+        return (None, *[float(v) for v in self.scales])
+
+
+class ResidualContinuity(_VelocityMetric):
+    entry = "ResidualContinuity"
+
+    def calc_both_pred_and_target(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        out = ops.eval_metrics(predicts, targets, masks, self._stds(), self.delta_meter, 0)
+        return out[EVAL_INDEX["ResidualContinuity"]], out[EVAL_INDEX["ResidualContinuityTarget"]]
+
+
+class AbsDiffDivergence(_VelocityMetric):
+    entry = "AbsDiffDivergence"
+
+
+class DiffOmegaVectorNorm(_VelocityMetric):
+    entry = "DiffOmegaNorm"
+
+    def __init__(self, scales: List[float], delta_meter: float = 5.0):
+        super().__init__(scales, delta_meter)
+        self.delta = delta_meter
+
+
+class DiffVelocityVectorNorm(_FusedMetric):
+    def __init__(self, scales: List[float], eps: float = 1e-30, lev: int = None):
+        super().__init__()
+        assert len(scales) == 3
+        _check_eps(eps)
+        self.scales, self.eps, self.lev = deepcopy(scales), eps, lev
+        self.entry = "DiffVelocityNorm" if lev is None else "DiffVelocityNormLev"
+
+    def _stds(self):
+        return (None, *[float(v) for v in self.scales])
+
+    def _lev(self):
+        return 0 if self.lev is None else int(self.lev)
+
+    def forward(self, predicts, targets, masks):
+        assert predicts.shape[1] == targets.shape[1] == 4  # channels == T, u, v, w
+        return super().forward(predicts, targets, masks)
+
+
+class AbsDiffTemperature(_FusedMetric):
+    def __init__(self, scale: float, eps: float = 1e-30, lev: int = None):
+        super().__init__()
+        _check_eps(eps)
+        self.scale, self.eps, self.lev = scale, eps, lev
+        self.entry = "AbsDiffTemperature" if lev is None else "AbsDiffTemperatureLev"
+
+    def _stds(self):
+        return (float(self.scale), None, None, None)
+
+    def _lev(self):
+        return 0 if self.lev is None else int(self.lev)
+
+    def forward(self, predicts, targets, masks):
+        assert predicts.shape[1] == targets.shape[1] == 4  # channels == T, u, v, w
+        return super().forward(predicts, targets, masks)
+
+
+class _MixedTerm(MixedDivergenceGradientL2Loss):
+    """loss_maker.py:453-519: one term of the mixed loss as a metric"""
+    term, wg, wd = 0, 0.0, 0.0
+
+    def __init__(self, scales: List[float], delta_meter: float = 5.0):
+        super().__init__(weight_gradient_loss=self.wg, weight_divergence_loss=self.wd, scales=scales,
+                         delta_meter=delta_meter)
+
+    def forward(self, predicts, targets, masks):
+        return self._terms(predicts, targets, masks)[self.term]
+
+
+class MixedDivergenceGradientL2LossMse(_MixedTerm):
+    term, wg, wd = 0, 0.0, 0.0
+
+
+class MixedDivergenceGradientL2LossGrdMse(_MixedTerm):
+    term, wg, wd = 1, 1.0, 0.0
+
+
+class MixedDivergenceGradientL2LossDivMse(_MixedTerm):
+    term, wg, wd = 2, 0.0, 1.0
+
+
+def merged_metric_scales(loss_fns) -> typing.Tuple[typing.Optional[float], ...]:
+    """union of the scales the fused metrics in ``loss_fns`` depend on (None where nobody cares or they disagree)"""
+    merged: typing.List[typing.Optional[float]] = [None] * 4
+    clash = [False] * 4
+    for fn in loss_fns:
+        if isinstance(fn, _FusedMetric):
+            for i, v in enumerate(fn._stds()):
+                if v is None:
+                    continue
+                if merged[i] is not None and merged[i] != v:
+                    clash[i] = True
+                merged[i] = v
+    return tuple(None if c else m for m, c in zip(merged, clash))

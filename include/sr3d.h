@@ -148,6 +148,32 @@ int sr3d_mixed_div_grad_l2_bwd(const void* p, const void* t, int B, int Z, int Y
                                float delta_meter, float w_g, float w_d, const void* term_weights, void* dLdp,
                                void* workspace, void* stream);
 
+/* ---- evaluation metrics (forward-only test pass) -------------------------------- */
+/* Every metric of the reference's final evaluation (script/train_model.py:366-379; modules at loss_maker.py:194-213,
+ * 522-741) from ONE pass over prediction, target and building mask.  p, t: (B,4,Z,Y,X); b: (B,1,Z,Y,X);
+ * stds = config['data']['stds'] (temperature scale, then the three velocity scales); `lev` is the z index of the
+ * *_LEV entries (the reference uses lev = 0).  out: SR3D_EVAL_COUNT floats in DEVICE memory. */
+enum {
+  SR3D_EVAL_L1 = 0,                      /* MyL1Loss                      loss_maker.py:194-202 */
+  SR3D_EVAL_L2 = 1,                      /* MyL2Loss                      :205-213 */
+  SR3D_EVAL_MASKED_L1 = 2,               /* MaskedL1Loss                  :522-536 */
+  SR3D_EVAL_MASKED_L2 = 3,               /* MaskedL2Loss                  :539-553 */
+  SR3D_EVAL_MASKED_L1_NEAR_WALL = 4,     /* MaskedL1LossNearWall          :556-574 */
+  SR3D_EVAL_MASKED_L2_NEAR_WALL = 5,     /* MaskedL2LossNearWall          :577-595 */
+  SR3D_EVAL_RESIDUAL_CONTINUITY = 6,     /* ResidualContinuity.forward    :598-615 */
+  SR3D_EVAL_RESIDUAL_CONTINUITY_TARGET = 7, /* ... .calc_both_pred_and_target, target part   :617-633 */
+  SR3D_EVAL_ABS_DIFF_TEMPERATURE = 8,    /* AbsDiffTemperature            :674-703 */
+  SR3D_EVAL_DIFF_VELOCITY_NORM = 9,      /* DiffVelocityVectorNorm        :636-671 */
+  SR3D_EVAL_ABS_DIFF_TEMPERATURE_LEV = 10, /* the same two at z == lev */
+  SR3D_EVAL_DIFF_VELOCITY_NORM_LEV = 11,
+  SR3D_EVAL_ABS_DIFF_DIVERGENCE = 12,    /* AbsDiffDivergence             :706-727 */
+  SR3D_EVAL_DIFF_OMEGA_NORM = 13,        /* DiffOmegaVectorNorm           :730-745 */
+  SR3D_EVAL_COUNT = 14
+};
+size_t sr3d_eval_metrics_workspace_bytes(int B, int Z, int Y, int X);
+int sr3d_eval_metrics(const void* p, const void* t, const void* b, int B, int Z, int Y, int X, const float stds[4],
+                      float delta_meter, int lev, void* out, void* workspace, void* stream);
+
 /* ---- optimizer -------------------------------------------------------------- */
 /* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based.  The
  * hyper-parameters are doubles, as in torch (1 - beta2 must be formed in double to match it). */
@@ -171,7 +197,8 @@ enum {
   SR3D_PROF_ADAM = 7,         /* fused Adam                                                  [byte] */
   SR3D_PROF_DATA = 8,         /* upsample+concat, mask pyramid, near-wall mask               [byte] */
   SR3D_PROF_PACK = 9,         /* weight packing / transforms and split-K reductions          [byte] */
-  SR3D_PROF_FAMILIES = 10,
+  SR3D_PROF_EVAL = 10,        /* fused evaluation metrics                                    [byte] */
+  SR3D_PROF_FAMILIES = 11,
   SR3D_PROF_DROPPED = 99      /* launches: records lost because the event pool was exhausted */
 };
 int sr3d_profile_enable(int on);

@@ -331,7 +331,47 @@ def default_width_fixture(name, hr, s, seed, mask_kind, loss_name):
     print(name, "pred", tuple(pred.shape), "loss", float(loss), "f64", float(l64))
 
 
+
+def metrics_fixture():
+    """the reference's evaluation metric modules (script/train_model.py:366-379 builds exactly these) on seeded
+    small inputs; inputs are regenerated on the test side (tests/helpers.py:synthetic_inputs)"""
+    from src import loss_maker as LM
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_inputs
+    stds = [8.4, 14.4, 21.6, 7.0]
+    out = {"stds": np.array(stds)}
+    for tag, (B, hr, seed, kind) in {"iid": (2, (8, 16, 24), 41, "iid"), "tower": (1, (16, 24, 40), 42, "tower")}.items():
+        _, b, y = synthetic_inputs(B, hr, 4, seed, kind)
+        g = torch.Generator().manual_seed(seed + 100)
+        p = y + 0.3 * (torch.rand(y.shape, generator=g) - 0.5)
+        fns = {"L1": LM.MyL1Loss(), "L2": LM.MyL2Loss(), "MaskedL1": LM.MaskedL1Loss(), "MaskedL2": LM.MaskedL2Loss(),
+               "MaskedL1NearWall": LM.MaskedL1LossNearWall(), "MaskedL2NearWall": LM.MaskedL2LossNearWall(),
+               "ResidualContinuity": LM.ResidualContinuity(stds[1:]),
+               "AbsDiffTemperature": LM.AbsDiffTemperature(stds[0]),
+               "DiffVelocityNorm": LM.DiffVelocityVectorNorm(stds[1:]),
+               "AbsDiffTemperatureLev": LM.AbsDiffTemperature(stds[0], lev=0),
+               "DiffVelocityNormLev": LM.DiffVelocityVectorNorm(stds[1:], lev=0),
+               "AbsDiffDivergence": LM.AbsDiffDivergence(stds[1:]),
+               "DiffOmegaNorm": LM.DiffOmegaVectorNorm(stds[1:])}
+        out[f"{tag}/meta"] = np.array(json.dumps(dict(B=B, hr=hr, seed=seed, kind=kind)))
+        for k, fn in fns.items():
+            out[f"{tag}/{k}"] = np.array(float(fn(p, y, b)), dtype=np.float64)
+        pr, tr = LM.ResidualContinuity(stds[1:]).calc_both_pred_and_target(p, y, b)
+        assert float(pr) == float(out[f"{tag}/ResidualContinuity"])
+        out[f"{tag}/ResidualContinuityTarget"] = np.array(float(tr), dtype=np.float64)
+        out[f"{tag}/Lev2/AbsDiffTemperatureLev"] = np.array(float(LM.AbsDiffTemperature(stds[0], lev=2)(p, y, b)))
+        out[f"{tag}/Lev2/DiffVelocityNormLev"] = np.array(float(LM.DiffVelocityVectorNorm(stds[1:], lev=2)(p, y, b)))
+        for nm, cls in (("Mse", LM.MixedDivergenceGradientL2LossMse), ("GrdMse", LM.MixedDivergenceGradientL2LossGrdMse),
+                        ("DivMse", LM.MixedDivergenceGradientL2LossDivMse)):
+            out[f"{tag}/Mixed{nm}"] = np.array(float(cls(stds[1:])(p, y, b)), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics.npz", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        metrics_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "default_width":   # only the (slow) default-width fixtures
         default_width_fixture("model_default_a.npz", (16, 64, 64), 4, 31, "tower", "MixedDivergenceGradientL2Loss")
         default_width_fixture("model_default_b.npz", (32, 64, 64), 2, 32, "iid", "L1")

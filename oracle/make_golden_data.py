@@ -13,8 +13,9 @@ sys.path.insert(0, os.path.join(HERE, "..", "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from data_fixture import CASES, write_synthetic_tree  # noqa: E402
-from src.dataloader import get_all_new_lr_data_dir_paths, split_into_train_valid_test_dirs  # noqa: E402
+from data_fixture import CASES, EVAL_CONFIG, HR32, write_synthetic_tree  # noqa: E402
+from src.dataloader import (get_all_new_lr_data_dir_paths, make_evaluation_dataloader_without_random_cropping,  # noqa: E402
+                            split_into_train_valid_test_dirs)
 from src.dataset import DatasetWithoutAligningResolution  # noqa: E402
 
 out = {}
@@ -31,5 +32,13 @@ with tempfile.TemporaryDirectory() as tmp:
             torch.manual_seed(100 + idx)
             lr, b, hr = ds[idx]
             out[f"{name}/{idx}/lr"], out[f"{name}/{idx}/b"], out[f"{name}/{idx}/hr"] = lr.numpy(), b.numpy(), hr.numpy()
+# the reference's own evaluation loader (dataloader.py:195-246) on a 32-level tree, LR levels 0-1 discarded
+with tempfile.TemporaryDirectory() as tmp:
+    root = write_synthetic_tree(tmp, HR=HR32, days=10)
+    loader = make_evaluation_dataloader_without_random_cropping(EVAL_CONFIG, root, batch_size=1, num_workers=0)
+    out["eval/len"] = np.array(len(loader))
+    out["eval/files"] = np.array([os.path.basename(f) for f in loader.dataset.hr_files])
+    for i, (lr, b, hr) in enumerate(loader):
+        out[f"eval/{i}/lr"], out[f"eval/{i}/b"], out[f"eval/{i}/hr"] = lr.numpy(), b.numpy(), hr.numpy()
 np.savez_compressed(os.path.join(HERE, "..", "tests", "golden", "dataset.npz"), **out)
 print("dataset.npz", len(out), "arrays")

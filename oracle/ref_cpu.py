@@ -462,3 +462,59 @@ def train_step(sd: StateDict, opt: AdamState, config: dict, x: Tensor, b: Tensor
     _, loss, _, grads = loss_and_grads(sd, config, x, b, t)
     opt.step(sd, grads)
     return float(loss)
+
+
+# --------------------------------------------------------------------------
+# evaluation metrics of the final test pass  (pytorch/src/loss_maker.py:84-191, 522-745;
+# called at pytorch/script/train_model.py:366-390)
+# --------------------------------------------------------------------------
+def vorticity(v: Tensor, delta: float, padding: int) -> Tensor:
+    """``_calc_vorticity_vector`` (loss_maker.py:163-191): curl of a 3-channel (u, v, w) field,
+    (dw/dy - dv/dz, du/dz - dw/dx, dv/dx - du/dy)."""
+    assert v.shape[1] == 3
+    gx, gy, gz = (central_diff(v, a, delta, padding) for a in ("x", "y", "z"))
+    return torch.cat([gy[:, 2:3] - gz[:, 1:2], gz[:, 0:1] - gx[:, 2:3], gx[:, 1:2] - gy[:, 0:1]], dim=1)
+
+
+def _interior_masked(field_fn, b: Tensor, q: Tensor, scales: Sequence[float], delta: float):
+    """shared body of ``calc_residual_continuity_eq`` / ``calc_vorticity_vector`` (loss_maker.py:84-113, 133-160):
+    field of the scaled velocity on the interior, zeroed inside buildings and next to walls; the voxel count is
+    sum(b) - sum(near) over the interior."""
+    sc = torch.tensor(list(scales), dtype=torch.float32)[None, :, None, None, None]   # fp32 like the reference
+    f = field_fn(sc * q[:, 1:], delta, 0)
+    near = near_wall_mask(b)
+    bi, ni = b[..., 1:-1, 1:-1, 1:-1], near[..., 1:-1, 1:-1, 1:-1]
+    f = f * bi
+    f = f * (1 - ni)
+    return f, bi.sum() - ni.sum()
+
+
+def eval_metrics(p: Tensor, t: Tensor, b: Tensor, stds: Sequence[float], delta: float = 5.0, lev: int = 0,
+                 eps: float = 1e-30) -> Dict[str, Tensor]:
+    """Every metric ``script/train_model.py:366-379`` evaluates (plus the L2 variants and the target-side residual of
+    ``ResidualContinuity.calc_both_pred_and_target``), keyed like ``_lib.EVAL_INDEX`` of the engine."""
+    d = p - t
+    ad, sq = d.abs(), d ** 2
+    m4 = torch.broadcast_to(b, ad.shape)
+    near = near_wall_mask(b)
+    n4 = torch.broadcast_to(near, ad.shape)
+    out = {"L1": ad.mean(), "L2": sq.mean(),
+           "MaskedL1": (m4 * ad).sum() / (m4.sum() + eps), "MaskedL2": (m4 * sq).sum() / (m4.sum() + eps),
+           "MaskedL1NearWall": (n4 * ad).sum() / (n4.sum() + eps), "MaskedL2NearWall": (n4 * sq).sum() / (n4.sum() + eps)}
+    rp, n1 = _interior_masked(divergence, b, p, stds[1:], delta)
+    rt, _ = _interior_masked(divergence, b, t, stds[1:], delta)
+    out["ResidualContinuity"] = rp.abs().sum() / n1
+    out["ResidualContinuityTarget"] = rt.abs().sum() / n1
+    out["AbsDiffDivergence"] = (rp - rt).abs().sum() / n1
+    op, _ = _interior_masked(vorticity, b, p, stds[1:], delta)
+    ot, _ = _interior_masked(vorticity, b, t, stds[1:], delta)
+    out["DiffOmegaNorm"] = torch.linalg.norm(op - ot, dim=1, keepdim=True).sum() / n1
+    sc = torch.tensor(list(stds[1:]), dtype=torch.float32)[None, :, None, None, None]
+    dv = torch.linalg.norm(p[:, 1:] * sc - t[:, 1:] * sc, dim=1, keepdim=True)
+    dT = (p[:, 0:1] - t[:, 0:1]).abs() * stds[0]
+    out["AbsDiffTemperature"] = (b * dT).sum() / (b.sum() + eps)
+    out["DiffVelocityNorm"] = (b * dv).sum() / (b.sum() + eps)
+    bl = b[:, :, lev]
+    out["AbsDiffTemperatureLev"] = (bl * dT[:, :, lev]).sum() / (bl.sum() + eps)
+    out["DiffVelocityNormLev"] = (bl * dv[:, :, lev]).sum() / (bl.sum() + eps)
+    return out

@@ -35,3 +35,12 @@ def write_synthetic_tree(tmp, HR=HR, days=5) -> pathlib.Path:
             np.save(d / f"{day}{t}00_HR.npy", hr)
             np.save(d / f"{day}{t}00_LR_x04.npy", lr)
     return root
+
+
+# evaluation loader (whole domain, 32 levels): a config['data'] section as in config/missing_below_43m.yml
+HR32 = (32, 8, 12)
+EVAL_CONFIG = {"data": {"data_dir_names": ["10"], "train_valid_test_ratios": [0.6, 0.2, 0.2],
+                        "means": [300.0, -6.5, -9.1, -3.5], "stds": [8.4, 14.4, 21.6, 7.0], "nan_value": 0.0,
+                        "hr_org_size": list(HR32), "hr_crop_size": list(HR32), "datasizes": {"train": None, "valid": None,
+                                                                                            "test": 3},
+                        "seed": 11, "lr_scaling": 0.95, "max_discarded_lr_z_index": 2, "scale_factor": 4}}

@@ -109,3 +109,16 @@ def test_model_without_level4(eng):
     assert m.down4 is None and m.up4 is None
     from oracle import ref_cpu as R
     assert list(m.state_dict().keys()) == [k for k, _ in R.param_shapes(cfg["model"])]
+
+
+def test_alias_submodules_are_not_imported_twice(eng):
+    """``sr3d_amd.src.x`` must be the same module object as ``3d-sr-micrometeorology_amd.src.x``: a second copy would
+    carry its own classes and break isinstance checks between them (optim_helper.evaluate vs loss_maker metrics)"""
+    import importlib
+
+    from sr3d_amd.src import loss_maker as via_alias
+    from sr3d_amd.src.optim_helper import evaluate
+    real = importlib.import_module("3d-sr-micrometeorology_amd.src.loss_maker")
+    assert via_alias is real
+    assert evaluate.__module__ == "3d-sr-micrometeorology_amd.src.optim_helper"
+    assert issubclass(via_alias.MaskedL1Loss, real._FusedMetric)

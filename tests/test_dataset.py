@@ -70,3 +70,35 @@ def test_ordered_split_matches_sklearn_for_every_fraction():
                 continue
             a, b = train_test_split(items, test_size=f, shuffle=False)
             assert (a, b) == tuple(_ordered_split(items, f)), (n, f)
+
+
+def test_evaluation_loader_matches_reference(tmp_path):
+    """whole-domain test loader (dataloader.py:195-246) with lr_scaling and max_discarded_lr_z_index > 0, against
+    batches the reference's own make_evaluation_dataloader_without_random_cropping produced on the same tree"""
+    import sr3d_amd  # noqa: F401
+    from data_fixture import EVAL_CONFIG, HR32
+    from sr3d_amd.src.dataloader import make_evaluation_dataloader_without_random_cropping
+    g = load_golden("dataset.npz")
+    root = write_synthetic_tree(tmp_path, HR=HR32, days=10)
+    loader = make_evaluation_dataloader_without_random_cropping(EVAL_CONFIG, root, batch_size=1, num_workers=0)
+    assert len(loader) == int(g["eval/len"]) == 3
+    assert [os.path.basename(f) for f in loader.dataset.hr_files] == list(g["eval/files"])
+    for i, (lr, b, hr) in enumerate(loader):
+        assert tuple(hr.shape) == (1, 4) + HR32 and tuple(lr.shape) == (1, 4, 8, 2, 3)
+        assert float(lr[:, :, :2].abs().max()) == 0.0          # the two lowest LR levels are discarded
+        for name, t in (("lr", lr), ("b", b), ("hr", hr)):
+            assert np.array_equal(t.numpy(), g[f"eval/{i}/{name}"], equal_nan=True), (i, name)
+
+
+def test_three_directory_sets_are_interleaved_chronologically(tmp_path):
+    """get_all_data_dir_paths (dataloader.py:20-60): per date the 04, 03, 05 sets in that order"""
+    import sr3d_amd  # noqa: F401
+    from sr3d_amd.src.dataloader import data_dirs_of_config, get_all_data_dir_paths
+    for n in ("03", "04", "05"):
+        for day in ("20130801", "20130802"):
+            (tmp_path / n / day).mkdir(parents=True)
+    got = [f"{p.parent.name}/{p.name}" for p in get_all_data_dir_paths(tmp_path)]
+    assert got == ["04/20130801", "03/20130801", "05/20130801", "04/20130802", "03/20130802", "05/20130802"]
+    assert data_dirs_of_config({"data": {"data_dir_names": ["03", "04", "05"]}}, tmp_path) == get_all_data_dir_paths(tmp_path)
+    with pytest.raises(Exception):
+        data_dirs_of_config({"data": {"data_dir_names": ["07"]}}, tmp_path)
