@@ -15,5 +15,6 @@ from .src.loss_maker import make_loss  # noqa: F401
 from .src.model_maker import make_model  # noqa: F401
 from .src.optim import FlatAdam  # noqa: F401
 from .src.ddp import GradAllReducer  # noqa: F401
+from .src.graph import GraphedTrainStep  # noqa: F401
 
 __version__ = "0.1.0"

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsr3d.so")
+# SR3D_LIBRARY: developer hook for A/B timing of two builds of the library (tools/layer_bench.py); never a fallback
+LIB_PATH = os.environ.get("SR3D_LIBRARY") or os.path.join(_HERE, "libsr3d.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED = 0, 1, 2, 3
@@ -62,6 +63,7 @@ SYMBOLS = {
     "sr3d_eval_metrics_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_eval_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _I, _P, _P, _P]),
     "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),
+    "sr3d_adam_step_device_counter": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _P, _P, _D, _P]),
     "sr3d_profile_enable": (_I, [_I]),
     "sr3d_profile_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

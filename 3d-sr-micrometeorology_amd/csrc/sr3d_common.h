@@ -7,6 +7,9 @@
 #include "../../include/sr3d.h"
 
 #define SR3D_MAX_SRC 4
+// most GEMM-K channels the Winograd stride-1 kernel takes (its per-workgroup channel-pointer table lives in LDS);
+// the model's largest is 2056 (input gradient of up3.up / up4.up).  Beyond it the direct kernel runs.
+#define SR3D_WINO_MAX_K 2560
 #define SR3D_MAX_TAPS 27
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -214,6 +214,56 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
   }
 }
 
+// Step bookkeeping on the DEVICE for a captured (hipGraph) training step: the host cannot advance a counter between
+// replays, so one thread increments it and derives the two bias-correction scalars exactly as the host path does
+// (double precision, then rounded to float).
+__global__ void adam_prepare_kernel(int* __restrict__ step, float* __restrict__ scalars, double lr, double beta1,
+                                    double beta2) {
+  const int t = *step + 1;
+  *step = t;
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  scalars[0] = (float)(lr / bc1);
+  scalars[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(kThreads) void adam_indirect_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                 float* __restrict__ m, float* __restrict__ v, long long n,
+                                                                 const float* __restrict__ scalars, float w1, float b2,
+                                                                 float w2, float eps, float gscale) {
+  const float step_size = scalars[0], inv_bc2_sqrt = scalars[1];
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = i0; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ONE(q)                                              \
+  {                                                         \
+    const float gr = gg.q * gscale;                         \
+    mm.q = mm.q + w1 * (gr - mm.q);                         \
+    vv.q = vv.q * b2 + w2 * gr * gr;                        \
+    const float den = sqrtf(vv.q) * inv_bc2_sqrt + eps;     \
+    pp.q = pp.q - step_size * (mm.q / den);                 \
+  }
+    ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (long long i = n4 * 4 + i0; i < n; i += stride) {
+    const float gr = g[i] * gscale;
+    const float mm = m[i] + w1 * (gr - m[i]);
+    const float vv = v[i] * b2 + w2 * gr * gr;
+    const float den = sqrtf(vv) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mm / den);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
 }  // namespace
 
 #define SR3D_ALIGN_CHECK(ptr, what) \
@@ -311,6 +361,26 @@ int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
   SrProfScope prof(SR3D_PROF_ADAM, 28.0 * (double)n, (hipStream_t)stream);   // p, m, v read+write, g read
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
                      (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_adam_step_device_counter(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, double lr,
+                                  double beta1, double beta2, double eps, void* step_counter, void* scalars,
+                                  double grad_scale, void* stream) {
+  SR3D_CHECK(param && grad && exp_avg && exp_avg_sq && step_counter && scalars && n > 0, SR3D_E_ARG,
+             "adam_step_device_counter: bad argument");
+  SR3D_ALIGN_CHECK(param, "adam_step_device_counter");
+  SR3D_ALIGN_CHECK(grad, "adam_step_device_counter");
+  SR3D_ALIGN_CHECK(exp_avg, "adam_step_device_counter");
+  SR3D_ALIGN_CHECK(exp_avg_sq, "adam_step_device_counter");
+  SrProfScope prof(SR3D_PROF_ADAM, 28.0 * (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)step_counter, (float*)scalars,
+                     lr, beta1, beta2);
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(adam_indirect_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
+                     (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, (const float*)scalars,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

@@ -440,7 +440,7 @@ inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
 // (the Winograd kernel keeps a table of channel pointers in LDS: at most 4096 channels on the K side, which is Cin
 // forward and n_dy * Cout for the input gradient - checked again there)
 inline bool use_wino(const sr3d_conv_desc_t* d) {
-  return d->stride == 1 && sr3d_wino_enabled() && d->Cin <= 4096 && d->Cout <= 4096;
+  return d->stride == 1 && sr3d_wino_enabled() && d->Cin <= SR3D_WINO_MAX_K && d->Cout <= SR3D_WINO_MAX_K;
 }
 inline int wino_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 32 * ((d->Cout + 15) / 16) : d->Cout;
@@ -875,7 +875,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   pk.K = K, pk.N = rows, pk.nchunks = p.nchunks;
   float* image = (float*)workspace;
 
-  if (use_wino(d) && K <= 4096) {
+  if (use_wino(d) && K <= SR3D_WINO_MAX_K) {
     // 1..4 gradient rows beyond a multiple of 64 (e.g. 193 = 3 * 64 + 1) would cost a whole 32-row Winograd tile per
     // voxel block: when they are the last channels of the last destination slice they take the small-N VALU kernel
     int rem = rows % 64;

@@ -52,8 +52,9 @@ constexpr int WVB = WVP * 16 * WKC * 32;    // V buffer [plane][xi][c][tile]
 constexpr int WUS = 3 * 16 * 2 * WKC * 32;  // U buffer [kz][xi][row tile][c][32 rows] = one packed image piece
 constexpr int WNT = 512;
 constexpr int WXB = 8 * 2 * 1024;           // epilogue exchange buffer [wave][value][32 rows x 32 tiles]
-constexpr int kWinoLdsFloats = (2 * WVB + 2 * WUS + 3 * WRB) > 2 * WXB ? (2 * WVB + 2 * WUS + 3 * WRB) : 2 * WXB;
-constexpr int WCT = 4096;                   // channel-pointer table entries (8 bytes each) behind the buffers
+constexpr int WNU = 3;                      // U buffers: the packed weights of chunk k+2 are in flight during chunk k
+constexpr int kWinoLdsFloats = (2 * WVB + WNU * WUS + 3 * WRB) > 2 * WXB ? (2 * WVB + WNU * WUS + 3 * WRB) : 2 * WXB;
+constexpr int WCT = SR3D_WINO_MAX_K;        // channel-pointer table entries (8 bytes each) behind the buffers
 constexpr size_t kWinoLds = (size_t)kWinoLdsFloats * 4 + (size_t)WCT * 8;
 static_assert(kWinoLds <= 160 * 1024, "LDS budget");
 
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   constexpr int WHY = G::HY, WHX = G::HX, WRE = G::RE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Vs = lds;                 // 2 buffers
-  float* Us = lds + 2 * WVB;       // 2 buffers
-  float* Rs = Us + 2 * WUS;        // 3 buffers
+  float* Us = lds + 2 * WVB;       // WNU buffers
+  float* Rs = Us + WNU * WUS;      // 3 buffers
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-  // ---- prologue: raw rows of chunks 0..2, U(0); V(0)
+  // ---- prologue: raw rows of chunks 0..2, U(0), U(1); V(0)
   dma_u(0, Us);
+  dma_u(1, Us + WUS);
   dma_raw(0, Rs);
   dma_raw(1, Rs + WRB);
   dma_raw(2, Rs + 2 * WRB);
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
                                                                              acc[(rt * 3 + pl) * 2 + xl], 0, 0, 0);
   };
   int rb = 0;   // raw buffer of chunk k
+  int ub = 0;   // U buffer of chunk k
   // One chunk per iteration.  Its kz = 0 fragments are already in set 0 (prefetched).  The single barrier sits
   // BEFORE the last MFMA group: by then every wave has read chunk k's fragments into registers and written its
   // share of V(k+1), so the last 12 MFMAs run while the next chunk's first fragments are fetched and the loop
@@ -229,13 +232,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
   for (int k = 0; k < p.nchunks; k++) {
     const int cur = k & 1;
     const int rb1 = rb == 2 ? 0 : rb + 1;
-    const float* U = Us + cur * WUS + fu;
+    const int ub1 = ub == WNU - 1 ? 0 : ub + 1, ub2 = ub1 == WNU - 1 ? 0 : ub1 + 1;
+    const float* U = Us + ub * WUS + fu;
     const float* V = Vs + cur * WVB + fv;
     const float* Rn = Rs + rb1 * WRB;       // raw rows of chunk k+1
     float* Vn = Vs + (cur ^ 1) * WVB;
     frags(U, V, 1, 1);
     tv_read(Rn, wave);
-    dma_u(k + 1, Us + (cur ^ 1) * WUS);
+    dma_u(k + 2, Us + ub2 * WUS);
     dma_raw(k + 3, Rs + rb * WRB);          // chunk k's raw buffer is free (its V was made during chunk k-1)
     mfmas(0);
     tv_write(Vn, wave);
@@ -247,13 +251,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
       tv_read(Rn, wave + 8);
       tv_write(Vn, wave + 8);
     }
-    // U(k+1) and everything older has landed; the 4 raw-row loads of chunk k+3 may stay in flight
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    // U(k+1) (issued one chunk ago) and everything older has landed; this chunk's 3 U(k+2) pieces and the 4 raw-row
+    // loads of chunk k+3 may stay in flight
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    frags(Us + (cur ^ 1) * WUS + fu, Vn + fv, 0, 0);   // chunk k+1, kz = 0
+    frags(Us + ub1 * WUS + fu, Vn + fv, 0, 0);   // chunk k+1, kz = 0
     mfmas(2);
     __builtin_amdgcn_sched_barrier(0);
     rb = rb1;
+    ub = ub1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray prefetches must not land in the exchange buffers
   __builtin_amdgcn_s_barrier();

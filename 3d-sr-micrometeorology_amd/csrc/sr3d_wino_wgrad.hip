@@ -77,7 +77,15 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
   // blocks of one split are neighbours in launch order: they walk the same columns at the same time, so the x rows
   // (shared by all row blocks) and dY rows (shared by all channel blocks) are served by L2 / MALL
   const int nblk_ = p.Npad / GNB, cblk_ = p.Cpad / 32;
-  const int split = blockIdx.x / (nblk_ * cblk_), q_ = blockIdx.x % (nblk_ * cblk_);
+  // ... and of one XCD: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2, so the
+  // logical index is made contiguous per XCD (ids congruent mod 8 -> one run of nwg / 8 logical blocks)
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
+  const int split = v / (nblk_ * cblk_), q_ = v % (nblk_ * cblk_);
   const int cb = q_ / nblk_, nb = q_ % nblk_;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
   const int YX = p.Y * p.X;

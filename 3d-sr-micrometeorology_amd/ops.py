@@ -348,3 +348,18 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
     L.check(L.lib.sr3d_adam_step(L.dev_ptr(param), L.dev_ptr(grad), L.dev_ptr(exp_avg), L.dev_ptr(exp_avg_sq), n,
                                  float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
                                  L.stream_ptr()), "sr3d_adam_step")
+
+
+def adam_step_device_counter_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                              lr: float, beta1: float, beta2: float, eps: float, step_counter: torch.Tensor,
+                              scalars: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """the same update with the step number in device memory (int32 tensor, incremented by the call): capturable"""
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+        raise ValueError("adam_step_device_counter_: buffer sizes differ")
+    if step_counter.dtype != torch.int32 or not step_counter.is_cuda or scalars.numel() < 2:
+        raise ValueError("adam_step_device_counter_: step_counter must be an int32 GPU tensor, scalars 2 floats")
+    L.check(L.lib.sr3d_adam_step_device_counter(L.dev_ptr(param), L.dev_ptr(grad), L.dev_ptr(exp_avg),
+                                                L.dev_ptr(exp_avg_sq), n, float(lr), float(beta1), float(beta2),
+                                                float(eps), C.c_void_p(step_counter.data_ptr()), L.dev_ptr(scalars),
+                                                float(grad_scale), L.stream_ptr()), "sr3d_adam_step_device_counter")

@@ -119,7 +119,7 @@ def cpu_baseline(cfg, budget_s=20.0):
                       f"volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
 
 
-def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, steps, warmup):
+def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, steps, warmup, graph=False):
     """W untimed + K timed training steps of one workload; returns wall time (max over ranks) and the per-family
     HIP-event totals of the timed steps"""
     cfg = make_config(loss_name)
@@ -128,8 +128,10 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     torch.manual_seed(42)
     model = sr3d_amd.make_model(cfg).to(dev)
     loss_fn = sr3d_amd.make_loss(cfg)
-    opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"])
+    opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"], capturable=graph)
     reducer = None
+    if graph and use_dist:
+        sys.exit("bench.py --graph captures the single-GPU step; the gradient all-reduce stays on the eager path")
     if use_dist:
         reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
         reducer.broadcast_parameters(opt.flat_param)
@@ -145,6 +147,12 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
         opt.step()
         return loss
 
+    if graph:      # the whole step captured once into a hipGraph; every step below is one replay
+        gstep = sr3d_amd.GraphedTrainStep(model, loss_fn, opt, x, b, y)
+
+        def step():  # noqa: F811
+            return gstep(x, b, y)
+
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -154,7 +162,8 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     for _ in range(warmup):
         step()
     fence()
-    L.lib.sr3d_profile_enable(1)        # creates its event pool here, outside the timed region
+    if not graph:                       # (event records cannot be part of a captured step)
+        L.lib.sr3d_profile_enable(1)    # creates its event pool here, outside the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -198,6 +207,8 @@ def main():
     ap.add_argument("--lr-grid", type=int, nargs=3, default=[20, 80, 80], metavar=("Z", "Y", "X"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short second workload")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the training step into a hipGraph and time replays (no per-kernel breakdown)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and the bucketed all-reduce even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
@@ -223,9 +234,10 @@ def main():
 
     batch = args.batch if args.batch is not None else (1 if world == 1 else 4)
     loss_name = args.loss if args.loss is not None else ("l1" if world == 1 else "mixed")
-    m = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, args.steps, args.warmup)
+    m = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, args.steps, args.warmup,
+                graph=args.graph)
     second = None
-    if not args.no_secondary and args.batch is None and args.loss is None:
+    if not args.no_secondary and args.batch is None and args.loss is None and not args.graph:
         sb, sl = (4, "mixed") if world == 1 else (1, "l1")
         second = measure(sr3d_amd, L, dev, rank, world, use_dist, sb, sl, args.lr_grid, min(args.steps, 3), 1)
         second["batch"], second["loss_name"] = sb, sl
@@ -268,7 +280,8 @@ def main():
             "vs_baseline": None,
             "dtype": "fp32",
             "data": "synthetic",
-            "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world),
+            "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world) +
+                       (" [hipGraph replay]" if args.graph else ""),
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "achieved": executed, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -180,6 +180,14 @@ int sr3d_eval_metrics(const void* p, const void* t, const void* b, int B, int Z,
 int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, double lr,
                    double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
 
+/* The same update with the step number kept in DEVICE memory: `step_counter` (int32, device) is incremented by the call
+ * itself and the bias corrections are derived from it on the device (`scalars`: 2 floats of device scratch), so a
+ * training step captured into a hipGraph advances correctly on every replay (the host-side `step` of sr3d_adam_step
+ * would be frozen into the graph). */
+int sr3d_adam_step_device_counter(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, long long n, double lr,
+                                  double beta1, double beta2, double eps, void* step_counter, void* scalars,
+                                  double grad_scale, void* stream);
+
 /* ---- measurement hook (bench.py's roofline leg; no reference counterpart) --------
  * When enabled, every launch of the kernels below is bracketed by two HIP events (taken from a pool that
  * sr3d_profile_enable(1) creates, so nothing is allocated inside a timed region) on the stream it is launched on.

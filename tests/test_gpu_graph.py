@@ -1,0 +1,77 @@
+"""hipGraph-captured training step (src/graph.py) == the eager step, bit for bit, step after step."""
+import pytest
+import torch
+
+from helpers import T, cfg_of, load_golden, sub, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available()
+    import sr3d_amd
+    return sr3d_amd
+
+
+def _setup(eng, cfg, sd, capturable):
+    model = eng.make_model(cfg)
+    if sd is not None:
+        model.load_state_dict(sd)
+    model.to(DEV)
+    return model, eng.make_loss(cfg), eng.FlatAdam(model.parameters(), lr=1e-3, capturable=capturable)
+
+
+def _eager(model, loss_fn, opt, x, b, y):
+    loss = loss_fn(model(x, b), y, b)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return float(loss.detach())
+
+
+@pytest.mark.parametrize("loss_name", ["mixed", "L1"])
+def test_graphed_steps_equal_eager_steps(eng, loss_name):
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = cfg_of(d), sub(d, "sd")
+    if loss_name == "L1":
+        cfg["train"]["loss"] = {"name": "L1"}
+    batches = [tuple(t.to(DEV) for t in synthetic_inputs(2, (16, 16, 16), 4, 50 + i, "iid")) for i in range(4)]
+    m1, lf1, o1 = _setup(eng, cfg, sd, capturable=False)
+    eager_losses = [_eager(m1, lf1, o1, *bt) for bt in batches]
+    m2, lf2, o2 = _setup(eng, cfg, sd, capturable=True)
+    step = eng.GraphedTrainStep(m2, lf2, o2, *batches[0])
+    assert o2.step_count == 0                      # the warm-up inside the constructor left no trace
+    graph_losses = [float(step(*bt)) for bt in batches]
+    assert graph_losses == eager_losses
+    assert o2.step_count == len(batches) == o1.step_count
+    assert torch.equal(o1.flat_param, o2.flat_param)
+    assert torch.equal(o1.exp_avg, o2.exp_avg) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
+    with pytest.raises(ValueError):
+        step(batches[0][0][:1], batches[0][1][:1], batches[0][2][:1])
+
+
+def test_capturable_adam_matches_host_counter(eng):
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(10007, generator=g)
+    a = torch.nn.Parameter(p0.clone().to(DEV))
+    b = torch.nn.Parameter(p0.clone().to(DEV))
+    oa, ob = eng.FlatAdam([a], lr=1e-3), eng.FlatAdam([b], lr=1e-3, capturable=True)
+    for i in range(5):
+        gr = torch.randn(10007, generator=g).to(DEV)
+        oa.flat_grad[:10007] = gr
+        ob.flat_grad[:10007] = gr
+        oa.step()
+        ob.step()
+    assert ob.step_count == 5
+    assert torch.equal(oa.flat_param, ob.flat_param)
+
+
+def test_graph_requirements_are_checked(eng):
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = cfg_of(d), sub(d, "sd")
+    m, lf, o = _setup(eng, cfg, sd, capturable=False)
+    x, b, y = (t.to(DEV) for t in synthetic_inputs(1, (16, 16, 16), 4, 3, "iid"))
+    with pytest.raises(ValueError):
+        eng.GraphedTrainStep(m, lf, o, x, b, y)
