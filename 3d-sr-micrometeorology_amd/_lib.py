@@ -56,6 +56,7 @@ SYMBOLS = {
     "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sr3d_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sr3d_near_wall": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sr3d_preprocess": (_I, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _I, _F, _I, _P]),
     "sr3d_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),

@@ -214,6 +214,38 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
   }
 }
 
+// Sample preprocessing of the reference's Dataset (pytorch/src/dataset.py:139-161,174,191-195) on the device:
+// out = nan_to_num(clamp?((scale * x - mean[c]) / std[c], 0, 1), nan = nan_value), then z levels < discard_z filled.
+// Same fp32 operations in the same order as the reference's torch expressions (IEEE subtract and divide), so the
+// result is bit-identical to the CPU path.
+struct PrepParams {
+  const float* x;
+  float* out;
+  long long total, vox;   // elements; voxels per channel
+  int C, YX, discard_z, clip;
+  float mean[8], stdv[8];
+  float scale, nan_value;
+};
+
+__global__ __launch_bounds__(kThreads) void preprocess_kernel(const PrepParams q) {
+  // hipcc contracts a * b - c into one fma by default (and __fmul_rn / __fsub_rn are plain operators in HIP, no
+  // barrier against it); torch rounds the product first, so contraction is switched off for this function
+#pragma clang fp contract(off)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q.total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long ch = i / q.vox;
+    const int c = (int)(ch % q.C);
+    const int z = (int)((i - ch * q.vox) / q.YX);
+    const float scaled = q.scale * q.x[i];   // plain operators: the pragma above governs THESE (the __f*_rn wrappers
+    float v = (scaled - q.mean[c]) / q.stdv[c];   // are header functions compiled with contraction allowed)
+    if (q.clip) v = v != v ? v : fminf(fmaxf(v, 0.f), 1.f);               // torch.clamp keeps NaN
+    if (v != v) v = q.nan_value;                                          // torch.nan_to_num(nan = nan_value)
+    else if (isinf(v)) v = v > 0.f ? 3.402823466e+38f : -3.402823466e+38f;   // ... and its +-inf defaults
+    if (z < q.discard_z) v = q.nan_value;
+    q.out[i] = v;
+  }
+}
+
 // Step bookkeeping on the DEVICE for a captured (hipGraph) training step: the host cannot advance a counter between
 // replays, so one thread increments it and derives the two bias-correction scalars exactly as the host path does
 // (double precision, then rounded to float).
@@ -362,6 +394,26 @@ int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
                      (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_preprocess(const void* x, void* out, int B, int C, int Z, int Y, int X, const float* means, const float* stds,
+                    float scaling, int clip, float nan_value, int discard_z, void* stream) {
+  SR3D_CHECK(x && out && means && stds && B > 0 && C > 0 && C <= 8 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG,
+             "preprocess: bad argument (1..8 channels)");
+  SR3D_CHECK(discard_z >= 0 && discard_z <= Z, SR3D_E_ARG, "preprocess: discard_z outside the grid");
+  PrepParams q{};
+  q.x = (const float*)x, q.out = (float*)out;
+  q.vox = (long long)Z * Y * X, q.total = (long long)B * C * q.vox;
+  q.C = C, q.YX = Y * X, q.discard_z = discard_z, q.clip = clip != 0;
+  for (int c = 0; c < C; c++) {
+    SR3D_CHECK(stds[c] != 0.f, SR3D_E_ARG, "preprocess: stds[%d] is zero", c);
+    q.mean[c] = means[c], q.stdv[c] = stds[c];
+  }
+  q.scale = scaling, q.nan_value = nan_value;
+  SrProfScope prof(SR3D_PROF_DATA, 8.0 * (double)q.total, (hipStream_t)stream);
+  hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(q.total)), dim3(kThreads), 0, (hipStream_t)stream, q);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

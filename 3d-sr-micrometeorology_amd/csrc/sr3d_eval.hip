@@ -62,9 +62,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // central difference exactly as the reference's depthwise convolution evaluates it: hi * w + lo * (-w)
-__device__ __forceinline__ float cdiff(float hi, float lo, float w) { return __fadd_rn(__fmul_rn(hi, w), __fmul_rn(lo, -w)); }
+// (contraction off: hipcc would otherwise fuse one product into an fma; the convolution rounds both products)
+__device__ __forceinline__ float cdiff(float hi, float lo, float w) {
+#pragma clang fp contract(off)
+  const float a = hi * w, b = lo * -w;
+  return a + b;
+}
 
 __global__ __launch_bounds__(kThreads) void eval_kernel(const EvalParams q) {
+#pragma clang fp contract(off)
   float acc[kAcc];
 #pragma unroll
   for (int i = 0; i < kAcc; i++) acc[i] = 0.f;
@@ -114,7 +120,8 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const EvalParams q) {
     float n2 = 0.f;
 #pragma unroll
     for (int c = 1; c < 4; c++) {
-      const float dv = __fsub_rn(__fmul_rn(pc[c], q.s[c]), __fmul_rn(tc[c], q.s[c]));
+      const float vp = pc[c] * q.s[c], vt = tc[c] * q.s[c];   // (contraction is off in this kernel)
+      const float dv = vp - vt;
       n2 += dv * dv;
     }
     const float dV = sqrtf(n2);

@@ -239,6 +239,25 @@ def near_wall_mask(b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def preprocess(x: torch.Tensor, means: Sequence[float], stds: Sequence[float], scaling: Optional[float] = None,
+               clip: bool = True, nan_value: float = 0.0, discard_z: int = 0) -> torch.Tensor:
+    """the reference Dataset's normalise / clamp / NaN-fill of one (B, C, Z, Y, X) tensor in physical units, on the
+    device (dataset.py:139-161, 174, 191-195); bit-identical to the CPU path of ``src/dataset.py``"""
+    x = x.contiguous()
+    if x.dim() != 5:
+        raise ValueError("preprocess expects (B, C, Z, Y, X)")
+    B, c, Z, Y, X = x.shape
+    if len(means) != c or len(stds) != c:
+        raise ValueError("preprocess: one mean / std per channel")
+    out = torch.empty_like(x)
+    m = (C.c_float * c)(*[float(v) for v in means])
+    sd = (C.c_float * c)(*[float(v) for v in stds])
+    L.check(L.lib.sr3d_preprocess(L.dev_ptr(x), L.dev_ptr(out), B, c, Z, Y, X, m, sd,
+                                  1.0 if scaling is None else float(scaling), int(bool(clip)), float(nan_value),
+                                  int(discard_z or 0), L.stream_ptr()), "sr3d_preprocess")
+    return out
+
+
 # ---------------------------------------------------------------- losses
 class L1LossFn(torch.autograd.Function):
     """mean |p - t| and its gradient in one pass (reference loss_maker.py:194-202)."""

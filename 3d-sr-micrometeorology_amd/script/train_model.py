@@ -85,7 +85,10 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         nan_value=config["data"]["nan_value"], num_workers=config["data"].get("num_workers", 2),
         datasizes=config["data"]["datasizes"], seed=config["data"]["seed"], lr_scaling=config["data"].get("lr_scaling"),
         max_discarded_lr_z_index=config["data"].get("max_discarded_lr_z_index"),
-        scale_factor=config["data"].get("scale_factor", 4))
+        scale_factor=config["data"].get("scale_factor", 4),
+        # engine extension (absent from the reference's YAML = off): normalise / clamp / NaN-fill on the GPU, one batch
+        # ahead of the step (src/device_pipeline.py); the batches are bit-identical to the CPU pipeline's
+        device_pipeline=torch.device("cuda", rank) if config["data"].get("device_pipeline", False) else None)
 
     model = sr3d_amd.make_model(config).to(rank)
     loss_fn = sr3d_amd.make_loss(config)

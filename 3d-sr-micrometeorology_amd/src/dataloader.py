@@ -67,15 +67,18 @@ def make_dataloaders(data_dirs, hr_3d_build_path, means=[0.0] * 4, stds=[1.0] * 
                      hr_org_size: tuple = (32, 320, 320), hr_crop_size: tuple = (16, 64, 64), rank: int = None,
                      world_size: int = None, batch_size: int = 32, num_workers: int = 2, seed: int = 0,
                      datasizes: typing.Dict[str, int] = {}, use_clipping: bool = True, lr_scaling: float = None,
-                     max_discarded_lr_z_index: int = None, scale_factor: int = 4, **kwargs):
-    """dataloader.py:107-192; per-rank batch = batch_size // world_size"""
+                     max_discarded_lr_z_index: int = None, scale_factor: int = 4, device_pipeline=None, **kwargs):
+    """dataloader.py:107-192; per-rank batch = batch_size // world_size.
+
+    ``device_pipeline`` (a cuda device or None): workers deliver raw windows, normalise / clamp / NaN-fill run on that
+    GPU one batch ahead of the consumer (src/device_pipeline.py); the batches are bit-identical either way."""
     loaders, samplers = {}, {}
     for kind in ["train", "valid", "test"]:
         dataset = DatasetWithoutAligningResolution(
             data_dirs=data_dirs[kind], hr_3d_build_path=hr_3d_build_path, means=means, stds=stds, nan_value=nan_value,
             hr_org_size=hr_org_size, hr_crop_size=hr_crop_size, datasize=datasizes.get(kind, None), seed=seed,
             use_clipping=use_clipping, lr_scaling=lr_scaling, max_discarded_lr_z_index=max_discarded_lr_z_index,
-            scale_factor=scale_factor)
+            scale_factor=scale_factor, raw=device_pipeline is not None)
         train = kind == "train"
         if world_size is None or rank is None:
             loaders[kind] = DataLoader(dataset, batch_size=batch_size, drop_last=train, shuffle=train, pin_memory=True,
@@ -87,6 +90,10 @@ def make_dataloaders(data_dirs, hr_3d_build_path, means=[0.0] * 4, stds=[1.0] * 
             loaders[kind] = DataLoader(dataset, sampler=samplers[kind], batch_size=batch_size // world_size,
                                        pin_memory=True, num_workers=num_workers, worker_init_fn=seed_worker,
                                        generator=get_torch_generator(seed), drop_last=train)
+        if device_pipeline is not None:
+            from .device_pipeline import DeviceBatchPipeline
+            loaders[kind] = DeviceBatchPipeline(loaders[kind], device_pipeline, means, stds, nan_value, use_clipping,
+                                                lr_scaling, max_discarded_lr_z_index)
         if rank in (None, 0):
             logger.info(f"{kind}: dataset size = {len(dataset)}, batch num = {len(loaders[kind])}")
     return loaders, samplers

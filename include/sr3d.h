@@ -130,6 +130,13 @@ int sr3d_avgpool2(const void* in, void* out, int B, int Z, int Y, int X, void* s
 /* near = calc_mask_near_build_wall(b)                       loss_maker.py:57-83 */
 int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* stream);
 
+/* Sample preprocessing of the reference's Dataset on the device (dataset.py:139-161, 174, 191-195):
+ * out = nan_to_num(clamp?((scaling * x - means[c]) / stds[c], 0, 1), nan = nan_value) for x: (B, C, Z, Y, X) in
+ * physical units (C <= 8; means / stds are HOST arrays); z levels below discard_z are then set to nan_value
+ * (max_discarded_lr_z_index).  Bit-identical to the CPU expressions of the reference. */
+int sr3d_preprocess(const void* x, void* out, int B, int C, int Z, int Y, int X, const float* means, const float* stds,
+                    float scaling, int clip, float nan_value, int discard_z, void* stream);
+
 /* ---- losses (forward value + dL/dp in one pass) --------------------------- */
 /* out[0] = mean|p-t| ; dLdp = sign(p-t)/n * grad_scale           MyL1Loss, loss_maker.py:194-202 */
 size_t sr3d_loss_workspace_bytes(int B, int Z, int Y, int X);
