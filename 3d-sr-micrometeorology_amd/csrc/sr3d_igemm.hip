@@ -72,28 +72,18 @@ struct IgemmCfg {
   static constexpr int HZ = (TZ - 1) * S_IN + (HI - LO) + 1;
   static constexpr int HY = (TY - 1) * S_IN + (HI - LO) + 1;
   static constexpr int HX = (TX - 1) * S_IN + (HI - LO) + 1;
-  // Stride 2: a halo row is stored DE-INTERLEAVED by x parity -- [even halo columns 0, 2, .. : 33 | pad | odd
-  // columns 1, 3, .. : 32] -- so that the 32 lanes of a B fragment (output x = lane, halo column 2 * lane + kx) read
-  // 32 consecutive floats for every tap instead of every second one (which was a 2-way bank conflict on every read).
-  static constexpr bool DEINT = S_IN == 2;
-  static constexpr int XODD = 34;                              // first odd column inside a de-interleaved row
-  static constexpr int HXD = DEINT ? 66 : HX;                  // row pitch in LDS
-  static constexpr int HSRC = HZ * HY * HX;                    // halo elements per channel (what is loaded)
-  static constexpr int HCH = HZ * HY * HXD;                    // floats per channel in LDS
+  static constexpr int HCH = HZ * HY * HX;
   static constexpr int HS = (KC * HCH + 3) & ~3;  // floats, keeps the weight image 16-B aligned
   static constexpr int WM = 4;
   static constexpr int CT = TZ * TY / WM;
-  // Stride 2 is also software-pipelined: the packed weights are double-buffered in LDS and the halo of chunk k+1
-  // travels in registers while chunk k is multiplied (the first version was load -> barrier -> MFMA -> barrier).
-  static constexpr bool PIPE = S_IN == 2;
-  static constexpr size_t lds_bytes(int ntaps) { return (size_t)(HS + (PIPE ? 2 : 1) * ntaps * KC * BN) * 4; }
+  static constexpr size_t lds_bytes(int ntaps) { return (size_t)(HS + ntaps * KC * BN) * 4; }
   static_assert(TZ * TY % WM == 0, "col tiles must split over waves");
 };
 
 template <int S_IN, int LO, int HI, int TZ, int TY, int RT, int KC>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   using C = IgemmCfg<S_IN, LO, HI, TZ, TY, RT, KC>;
-  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, CT = C::CT, BN = C::BN, HXD = C::HXD;
+  constexpr int HY = C::HY, HX = C::HX, HCH = C::HCH, CT = C::CT, BN = C::BN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;
   float* Ws = lds + C::HS;
@@ -142,17 +132,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int a_lane = (lane >> 5) * BN + (lane & 31);
-  const int b_lane = (lane >> 5) * HCH + (lane & 31) * (C::DEINT ? 1 : S_IN);
+  const int b_lane = (lane >> 5) * HCH + (lane & 31) * S_IN;
   int b_ct[CT];
 #pragma unroll
   for (int j = 0; j < CT; j++) {
     const int ct = wm * CT + j;
-    b_ct[j] = ((ct / TY) * S_IN * HY + (ct % TY) * S_IN) * HXD + b_lane;
+    b_ct[j] = ((ct / TY) * S_IN * HY + (ct % TY) * S_IN) * HX + b_lane;
   }
-  // spatial offsets of this thread's halo elements (independent of the chunk); -1 = outside the grid.
-  // hpos: where the element goes inside one channel of the LDS tile (de-interleaved rows for stride 2).
-  constexpr int NI = (C::HSRC + 255) / 256;
-  int hoff[NI], hpos[NI];
+  // spatial offsets of this thread's halo elements (independent of the chunk); -1 = outside the grid
+  constexpr int NI = (HCH + 255) / 256;
+  int hoff[NI];
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int r = tid + i * 256;
@@ -161,48 +150,49 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int hy = r2 / HX;
     const int hx = r2 - hy * HX;
     const int gz = gz0 + hz, gy = gy0 + hy, gx = gx0 + hx;
-    const bool ok = r < C::HSRC && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY &&
+    const bool ok = r < HCH && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY &&
                     (unsigned)gx < (unsigned)p.IX;
     hoff[i] = ok ? (gz * p.IY + gy) * p.IX + gx : -1;
-    hpos[i] = r < C::HSRC ? (hz * HY + hy) * HXD + (C::DEINT ? ((hx & 1) ? C::XODD + (hx >> 1) : (hx >> 1)) : hx) : -1;
   }
   const int wblock = ntaps * KC * BN;  // floats per (nblk, chunk)
   const int ninstr = (wblock + 255) / 256;  // 1 KiB LDS-DMA pieces (the last one may be partial: wblock % 128 == 0)
 
-  // one chunk of the K loop: KC channels x all taps
-  auto dma_weights = [&](const int chunk, float* dst) {
-    const float* gw = wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
-    for (int i = wave; i < ninstr; i += 4)
-      if (i * 256 + lane * 4 < wblock)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
-  };
-  float hv[KC][NI];
-  // input halo tile [KC][HZ][HY][HX] -> registers, zero outside the grid / beyond K.  The channel is wave-uniform
-  // (scalar source select), the spatial offsets were computed once before the chunk loop.
-  auto load_halo = [&](const int chunk) {
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    // ---- weights: contiguous block, asynchronous global -> LDS (no VGPRs)
+    {
+      const float* gw = wp + (size_t)(nblk * p.nchunks + chunk) * wblock;
+      for (int i = wave; i < ninstr; i += 4)
+        if (i * 256 + lane * 4 < wblock)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + i * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(Ws + i * 256), 16, 0, 0);
+    }
+    // ---- input halo tile [KC][HZ][HY][HX], zero outside the grid / beyond K.
+    // The channel is wave-uniform (scalar source select), the spatial offsets
+    // were computed once before the chunk loop.
+    {
+      float v[KC][NI];
 #pragma unroll
-    for (int c = 0; c < KC; c++) {
-      const int gc = chunk * KC + c;
-      const float* base = nullptr;
-      if (gc < p.K) {
-        const int si = cat_find(p.in, gc);
-        base = p.in.ptr[si] + (long long)b * p.in.bstride[si] + (long long)(gc - p.in.cbeg[si]) * IZYX;
+      for (int c = 0; c < KC; c++) {
+        const int gc = chunk * KC + c;
+        const float* base = nullptr;
+        if (gc < p.K) {
+          const int si = cat_find(p.in, gc);
+          base = p.in.ptr[si] + (long long)b * p.in.bstride[si] + (long long)(gc - p.in.cbeg[si]) * IZYX;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[c][i] = (base != nullptr && hoff[i] >= 0) ? base[hoff[i]] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < NI; i++) hv[c][i] = (base != nullptr && hoff[i] >= 0) ? base[hoff[i]] : 0.f;
+      for (int c = 0; c < KC; c++)
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+          if (tid + i * 256 < HCH) Hs[c * HCH + tid + i * 256] = v[c][i];
     }
-  };
-  auto store_halo = [&]() {
-#pragma unroll
-    for (int c = 0; c < KC; c++)
-#pragma unroll
-      for (int i = 0; i < NI; i++)
-        if (hpos[i] >= 0) Hs[c * HCH + hpos[i]] = hv[c][i];
-  };
-  auto multiply = [&](const float* W) {
+    __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA has landed)
+
     for (int t = 0; t < ntaps; t++) {
-      const float* wt = W + t * (KC * BN) + a_lane;
+      const float* wt = Ws + t * (KC * BN) + a_lane;
       const float* ht = Hs + tap_off[t];
 #pragma unroll
       for (int kk = 0; kk < KC / 2; kk++) {
@@ -216,91 +206,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
           for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
       }
-    }
-  };
-
-  // Stride-2 forward: all 27 taps, fully unrolled with compile-time LDS offsets (no per-tap scalar load of the offset
-  // table, which one wave per SIMD cannot hide) so that the scheduler can keep the fragment reads of the next taps
-  // in flight under the MFMAs of the current one.
-  // ... and the next chunk's traffic is issued BETWEEN the k-steps (one halo load or one weight piece per step): the
-  // lone wave of a SIMD can issue ~10 other instructions in the shadow of each MFMA, but nothing hides a block of
-  // 28 loads + 7 LDS-DMA pieces issued at a chunk boundary, when the matrix pipe has already drained.
-  const float* hbase[KC];        // channel base pointers of the chunk being prefetched (wave-uniform)
-  auto halo_bases = [&](const int chunk) {
-#pragma unroll
-    for (int c = 0; c < KC; c++) {
-      const int gc = chunk * KC + c;
-      hbase[c] = nullptr;
-      if (gc < p.K) {
-        const int si = cat_find(p.in, gc);
-        hbase[c] = p.in.ptr[si] + (long long)b * p.in.bstride[si] + (long long)(gc - p.in.cbeg[si]) * IZYX;
-      }
-    }
-  };
-  auto multiply_pipelined = [&](const float* W, const int next_chunk, float* Wnext) {
-    const float* wt = W + a_lane;
-    constexpr int NS = 27 * (KC / 2);          // k-steps of one chunk: (tap, channel pair)
-    constexpr int NH = KC * NI;                // halo loads per thread and chunk
-    constexpr int NW = (27 * KC * BN + 1023) / 1024;   // LDS-DMA rounds (4 waves x 1 KiB) of one weight block
-    static_assert(NH + NW <= NS, "prefetch slots");
-    const bool more = next_chunk < p.nchunks;
-    if (more) halo_bases(next_chunk);
-    const float* gw = wp + (size_t)(nblk * p.nchunks + (more ? next_chunk : 0)) * wblock;
-    float a[2][RT], bb[2][CT];
-    auto fetch = [&](const int s_, const int set) {
-      const int t = s_ / (KC / 2), kk = s_ % (KC / 2);
-      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
-      const int off = (kz * HY + ky) * HXD + (C::DEINT ? (kx == 1 ? C::XODD : kx >> 1) : kx);
-#pragma unroll
-      for (int i = 0; i < RT; i++) a[set][i] = wt[t * (KC * BN) + (2 * kk) * BN + i * 32];
-#pragma unroll
-      for (int j = 0; j < CT; j++) bb[set][j] = Hs[off + (2 * kk) * HCH + b_ct[j]];
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int s_ = 0; s_ < NS; s_++) {
-      if (s_ + 1 < NS) fetch(s_ + 1, (s_ + 1) & 1);      // a whole k-step (RT x CT MFMAs) ahead of its use
-      if (s_ < NH) {                                      // one halo element of the next chunk
-        const int c = s_ / NI, i = s_ % NI;
-        hv[c][i] = (more && hbase[c] != nullptr && hoff[i] >= 0) ? hbase[c][hoff[i]] : 0.f;
-      } else if (s_ - NH < NW) {                          // weight pieces of the next chunk (1 KiB each, 4 waves)
-        const int piece = wave + 4 * (s_ - NH);
-        if (more && piece * 256 + lane * 4 < wblock)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw + piece * 256 + lane * 4),
-                                           (__attribute__((address_space(3))) void*)(Wnext + piece * 256), 16, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < RT; i++)
-#pragma unroll
-        for (int j = 0; j < CT; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][i], bb[s_ & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if constexpr (C::PIPE) {
-    // chunk k multiplies from Ws[k & 1] / Hs while the weights of chunk k+1 (LDS-DMA into the other buffer) and
-    // its halo (global loads into registers) are in flight; they are waited for at the top of the next iteration
-    // (the barrier's vmcnt(0)), after a whole chunk of MFMAs.
-    // (buffer addresses are formed by arithmetic on the LDS base: a pointer picked from an array would decay to a
-    // generic pointer and turn every fragment read into a flat load)
-    dma_weights(0, Ws);
-    load_halo(0);
-    for (int chunk = 0; chunk < p.nchunks; chunk++) {
-      __syncthreads();   // chunk-1 has been multiplied by every wave; weights + halo registers of `chunk` landed
-      store_halo();
-      __syncthreads();
-      multiply_pipelined(Ws + (chunk & 1) * wblock, chunk + 1, Ws + ((chunk + 1) & 1) * wblock);
-    }
-  } else {
-    for (int chunk = 0; chunk < p.nchunks; chunk++) {
-      __syncthreads();  // everyone is done reading the previous chunk
-      dma_weights(chunk, Ws);   // contiguous block, asynchronous global -> LDS (no VGPRs)
-      load_halo(chunk);
-      store_halo();
-      __syncthreads();  // (hipcc drains vmcnt here: the LDS-DMA has landed)
-      multiply(Ws);
     }
   }
 
@@ -730,10 +635,7 @@ int launch(IgemmParams p, int B, const RowPlan& rp, const float* image, hipStrea
   return rc;
 }
 
-// tap t = (kz, ky, kx) -> float offset inside one channel of the LDS halo tile.  `deint`: stride-2 rows are stored
-// de-interleaved by x parity (IgemmCfg::DEINT): halo column kx of output x is column x of the even part for
-// kx = 0, of the odd part for kx = 1, and column x + 1 of the even part for kx = 2.
-void full_taps(IgemmParams& p, int HY, int HXD, bool mirrored, bool deint = false, int xodd = 0) {
+void full_taps(IgemmParams& p, int HY, int HX, bool mirrored) {
   p.ntaps = 27;
   for (int kz = 0; kz < 3; kz++)
     for (int ky = 0; ky < 3; ky++)
@@ -741,8 +643,7 @@ void full_taps(IgemmParams& p, int HY, int HXD, bool mirrored, bool deint = fals
         const int t = (kz * 3 + ky) * 3 + kx;
         // forward: input offset d = k-1 -> (d-LO) = k ; stride-1 backward: d = 1-k -> (d-LO) = 2-k
         const int a = mirrored ? 2 - kz : kz, b = mirrored ? 2 - ky : ky, c = mirrored ? 2 - kx : kx;
-        const int xo = deint ? (c == 1 ? xodd : c >> 1) : c;
-        p.tap_off[t] = (a * HY + b) * HXD + xo;
+        p.tap_off[t] = (a * HY + b) * HX + c;
       }
 }
 
@@ -762,8 +663,8 @@ inline int fwd_rows(const sr3d_conv_desc_t* d, int kind) {
 // the forward launch plan depends only on the descriptor, so sr3d_pack_weights and sr3d_*_fwd agree on it
 RowPlan fwd_plan(const sr3d_conv_desc_t* d, int rows, bool gated) {
   const int oz = out_dim(d->Z, d->stride), oy = out_dim(d->Y, d->stride), ox = out_dim(d->X, d->stride);
-  // (stride 2 runs the pipelined variant: 128-row blocks, one workgroup per CU with double-buffered weights)
-  return row_plan(rows, tiles_of(d->B, oz, oy, ox, d->stride == 1 ? 2 : 1, 4), gated, 4);
+  // stride 2: the halo tile is 2x larger per voxel; 64-row blocks keep two workgroups resident per CU
+  return row_plan(rows, tiles_of(d->B, oz, oy, ox, d->stride == 1 ? 2 : 1, 4), gated, d->stride == 1 ? 4 : 2);
 }
 
 int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, IgemmParams& p, int dst_scale,
@@ -784,7 +685,7 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
     return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
   }
   using C = IgemmCfg<2, -1, 1, 1, 4, 4, kKC>;
-  full_taps(p, C::HY, C::HXD, false, true, C::XODD);
+  full_taps(p, C::HY, C::HX, false);
   return launch<2, -1, 1, 1, 4>(p, d->B, rp, image, st);
 }
 
