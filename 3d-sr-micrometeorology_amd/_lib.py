@@ -22,7 +22,8 @@ ACT_CODE = {None: ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU}
 EVAL_INDEX = {"L1": 0, "L2": 1, "MaskedL1": 2, "MaskedL2": 3, "MaskedL1NearWall": 4, "MaskedL2NearWall": 5,
               "ResidualContinuity": 6, "ResidualContinuityTarget": 7, "AbsDiffTemperature": 8, "DiffVelocityNorm": 9,
               "AbsDiffTemperatureLev": 10, "DiffVelocityNormLev": 11, "AbsDiffDivergence": 12, "DiffOmegaNorm": 13}
-EVAL_COUNT = 14
+EVAL_SUMS = {"abs": 14, "mask_abs": 15, "sq": 16, "mask_sq": 17, "mask": 18}
+EVAL_COUNT = 19
 
 
 class Slice(C.Structure):
@@ -61,6 +62,7 @@ SYMBOLS = {
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_fwd_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
     "sr3d_mixed_div_grad_l2_bwd": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _F, _F, _P, _P, _P, _P]),
+    "sr3d_weighted_lp_bwd": (_I, [_P, _P, _P, _I, _I, _LL, _I, _P, _P, _P]),
     "sr3d_eval_metrics_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_eval_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _I, _P, _P, _P]),
     "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),

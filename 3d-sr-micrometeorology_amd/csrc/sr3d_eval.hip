@@ -204,6 +204,10 @@ __global__ __launch_bounds__(64) void eval_final_kernel(const EvalParams q, int 
   o[SR3D_EVAL_DIFF_VELOCITY_NORM_LEV] = F(A_V_LEV) / (F(A_B_LEV) + eps);
   o[SR3D_EVAL_ABS_DIFF_DIVERGENCE] = F(A_DDIV) / n_grid;
   o[SR3D_EVAL_DIFF_OMEGA_NORM] = F(A_OMEGA) / n_grid;
+  // raw sums (the weighted losses of loss_maker.py:216-255 combine them with a run-time weight)
+  o[SR3D_EVAL_SUM_ABS] = F(A_ABS), o[SR3D_EVAL_SUM_MASK_ABS] = F(A_B_ABS);
+  o[SR3D_EVAL_SUM_SQ] = F(A_SQ), o[SR3D_EVAL_SUM_MASK_SQ] = F(A_B_SQ);
+  o[SR3D_EVAL_SUM_MASK] = F(A_B);
 }
 
 int blocks_for(long long vox) {

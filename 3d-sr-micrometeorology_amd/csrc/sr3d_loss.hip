@@ -280,6 +280,20 @@ inline int grid_for(long long n, int per_thread) {
   return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
 }
 
+__global__ __launch_bounds__(kThreads) void weighted_lp_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                                   const float* __restrict__ m, long long total, long long vox,
+                                                                   int Cc, int power, const float* __restrict__ coef,
+                                                                   float* __restrict__ g) {
+  const float c_in = coef[0], c_out = coef[1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long ch = i / vox;
+    const float mv = m[(ch / Cc) * vox + (i - ch * vox)];
+    const float d = p[i] - t[i];
+    const float e = power == 1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+    g[i] = e * (mv * c_in + (1.f - mv) * c_out);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,6 +350,19 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
     hipLaunchKernelGGL(mix_pass2_kernel, dim3(grid_for(vox, 1)), dim3(kThreads), 0, (hipStream_t)stream, q);
     SR3D_HIP(hipGetLastError());
   }
+  return SR3D_OK;
+}
+
+int sr3d_weighted_lp_bwd(const void* p, const void* t, const void* b, int B, int C, long long voxels, int power,
+                         const void* coef, void* dLdp, void* stream) {
+  SR3D_CHECK(p && t && b && coef && dLdp && B > 0 && C > 0 && voxels > 0, SR3D_E_ARG, "weighted_lp_bwd: bad argument");
+  SR3D_CHECK(power == 1 || power == 2, SR3D_E_ARG, "weighted_lp_bwd: power must be 1 or 2");
+  const long long total = (long long)B * C * voxels;
+  SrProfScope prof(SR3D_PROF_LOSS, (12.0 + 4.0 / C) * (double)total, (hipStream_t)stream);
+  hipLaunchKernelGGL(weighted_lp_bwd_kernel, dim3(grid_for(total, 1)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)p, (const float*)t, (const float*)b, total, voxels, C, power, (const float*)coef,
+                     (float*)dLdp);
+  SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 

@@ -357,6 +357,38 @@ def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequen
     return out
 
 
+class WeightedLpFn(torch.autograd.Function):
+    """WeightedL1Loss / WeightedL2Loss (reference loss_maker.py:216-255):
+    (w * sum_in(e) / (N_in + 1) + sum_out(e) / (N_out + 1)) / (w + 1) with e = |p - t| or (p - t)^2, `in` = mask 1
+    (outside buildings), the mask broadcast over the channels.  The five sums come out of the fused evaluation pass;
+    the gradient is one streaming kernel."""
+
+    @staticmethod
+    def forward(ctx, p, t, b, weight: float, power: int):
+        p, t, b = p.contiguous(), t.detach().contiguous(), b.detach().contiguous()
+        B, c = p.shape[0], p.shape[1]
+        sums = eval_metrics(p, t, b, (None,) * 4)
+        k = L.EVAL_SUMS
+        s_all, s_in = (sums[k["abs"]], sums[k["mask_abs"]]) if power == 1 else (sums[k["sq"]], sums[k["mask_sq"]])
+        n_in = c * sums[k["mask"]]
+        n_out = float(p.numel()) - n_in
+        w = float(weight)
+        loss = (w * s_in / (n_in + 1.0) + (s_all - s_in) / (n_out + 1.0)) / (w + 1.0)
+        ctx.save_for_backward(p, t, b, torch.stack([w / ((n_in + 1.0) * (w + 1.0)), 1.0 / ((n_out + 1.0) * (w + 1.0))]))
+        ctx.power = power
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, b, coef = ctx.saved_tensors
+        coef = (coef * gout).to(torch.float32).contiguous()
+        g = torch.empty_like(p)
+        B, c = p.shape[0], p.shape[1]
+        L.check(L.lib.sr3d_weighted_lp_bwd(L.dev_ptr(p), L.dev_ptr(t), L.dev_ptr(b), B, c, p[0, 0].numel(), ctx.power,
+                                           L.dev_ptr(coef), L.dev_ptr(g), L.stream_ptr()), "sr3d_weighted_lp_bwd")
+        return g, None, None, None, None
+
+
 # ---------------------------------------------------------------- optimizer
 def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float,
                beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0) -> None:

@@ -31,8 +31,15 @@ def make_loss(config: dict) -> nn.Module:
     if name == "L2":
         logger.info("L2 loss is created.")
         return MyL2Loss()
-    # WeightedL1 / WeightedL2 / MixedGradientL2Loss (loss_maker.py:27-38) are not on the hot path
-    # named by BASELINE.json and have no fused kernel yet.
+    if name == "WeightedL1":
+        logger.info("Weighted L1 loss is created.")
+        return WeightedL1Loss(config["train"]["loss"]["weight_outside_building"])
+    if name == "WeightedL2":
+        logger.info("Weighted L2 loss is created.")
+        return WeightedL2Loss(config["train"]["loss"]["weight_outside_building"])
+    if name == "MixedGradientL2Loss":
+        logger.info("Mixed gradient L2 loss is created.")
+        return MixedGradientL2Loss(weight_gradient_loss=config["train"]["loss"].get("weight_gradient_loss", None))
     raise NotImplementedError(f"{name} is not supported.")
 
 
@@ -90,6 +97,45 @@ class MixedDivergenceGradientL2Loss(nn.Module):
 
     def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
         return self._terms(predicts, targets, masks)[3]
+
+
+class WeightedL1Loss(nn.Module):
+    """loss_maker.py:216-232"""
+    power = 1
+
+    def __init__(self, weight_outside_building: float):
+        super().__init__()
+        self.weight = weight_outside_building
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        return ops.WeightedLpFn.apply(predicts, targets, masks, float(self.weight), self.power)
+
+
+class WeightedL2Loss(WeightedL1Loss):
+    """loss_maker.py:235-255"""
+    power = 2
+
+
+class MixedGradientL2Loss(nn.Module):
+    """loss_maker.py:258-301: mse + w_g * grd_mse -- the mixed divergence-gradient loss without its divergence term
+    (same masks, same 4 * sum(M) + 1 denominator)"""
+
+    def __init__(self, weight_gradient_loss: float):
+        super().__init__()
+        self.weight_gradient_loss = weight_gradient_loss
+        logger.info(f"weight grad loss = {self.weight_gradient_loss}")
+
+    def _off(self) -> bool:
+        return self.weight_gradient_loss is None or self.weight_gradient_loss == 0
+
+    def calc_loss_terms(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        t = ops.MixedLossFn.apply(predicts, targets, masks, [1.0, 1.0, 1.0], 5.0,
+                                  0.0 if self._off() else float(self.weight_gradient_loss), 0.0)
+        return (t[0], None) if self._off() else (t[0], t[1])
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        mse, grd = self.calc_loss_terms(predicts=predicts, targets=targets, masks=masks)
+        return mse if self._off() else mse + self.weight_gradient_loss * grd
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -148,6 +148,12 @@ int sr3d_mixed_div_grad_l2_fwd_bwd(const void* p, const void* t, const void* b, 
                                    const float scales[3], float delta_meter, float w_g, float w_d,
                                    void* terms_out, void* dLdp, void* workspace, void* stream);
 
+/* Gradient of WeightedL1Loss / WeightedL2Loss (loss_maker.py:216-255):
+ *   dLdp = e'(p - t) * (b * coef[0] + (1 - b) * coef[1]),   e = |.| (power 1) or (.)^2 (power 2),
+ * coef: 2 floats in DEVICE memory (the region weights divided by their voxel counts, times the upstream gradient). */
+int sr3d_weighted_lp_bwd(const void* p, const void* t, const void* b, int B, int C, long long voxels, int power,
+                         const void* coef, void* dLdp, void* stream);
+
 /* dLdp = d(wts[0]*mse + wts[1]*grd_mse + wts[2]*div_mse)/dp with the three weights read from DEVICE memory
  * (autograd / GradNorm, gradnorm.py:95-100, differentiate individual terms); reuses the workspace a previous
  * sr3d_mixed_div_grad_l2_fwd_bwd call with the same arguments filled. */
@@ -175,7 +181,12 @@ enum {
   SR3D_EVAL_DIFF_VELOCITY_NORM_LEV = 11,
   SR3D_EVAL_ABS_DIFF_DIVERGENCE = 12,    /* AbsDiffDivergence             :706-727 */
   SR3D_EVAL_DIFF_OMEGA_NORM = 13,        /* DiffOmegaVectorNorm           :730-745 */
-  SR3D_EVAL_COUNT = 14
+  SR3D_EVAL_SUM_ABS = 14,                /* raw sums over the 4 channels: sum |p - t|, sum b |p - t|,            */
+  SR3D_EVAL_SUM_MASK_ABS = 15,           /* sum (p - t)^2, sum b (p - t)^2 and sum b (one channel) -- what the      */
+  SR3D_EVAL_SUM_SQ = 16,                 /* weighted losses (loss_maker.py:216-255) are made of                     */
+  SR3D_EVAL_SUM_MASK_SQ = 17,
+  SR3D_EVAL_SUM_MASK = 18,
+  SR3D_EVAL_COUNT = 19
 };
 size_t sr3d_eval_metrics_workspace_bytes(int B, int Z, int Y, int X);
 int sr3d_eval_metrics(const void* p, const void* t, const void* b, int B, int Z, int Y, int X, const float stds[4],

@@ -364,6 +364,14 @@ def metrics_fixture():
         for nm, cls in (("Mse", LM.MixedDivergenceGradientL2LossMse), ("GrdMse", LM.MixedDivergenceGradientL2LossGrdMse),
                         ("DivMse", LM.MixedDivergenceGradientL2LossDivMse)):
             out[f"{tag}/Mixed{nm}"] = np.array(float(cls(stds[1:])(p, y, b)), dtype=np.float64)
+        # the other make_loss branches (loss_maker.py:27-38): value and dL/dp
+        for nm, fn in (("WeightedL1", LM.WeightedL1Loss(3.0)), ("WeightedL2", LM.WeightedL2Loss(0.5)),
+                       ("MixedGradientL2", LM.MixedGradientL2Loss(2.0)), ("MixedGradientL2_off", LM.MixedGradientL2Loss(None))):
+            pp = p.clone().requires_grad_(True)
+            v = fn(pp, y, b)
+            v.backward()
+            out[f"{tag}/{nm}"] = np.array(float(v), dtype=np.float64)
+            out[f"{tag}/{nm}/dp"] = npy(pp.grad)
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
     print("metrics.npz", len(out))
 

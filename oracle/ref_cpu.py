@@ -518,3 +518,18 @@ def eval_metrics(p: Tensor, t: Tensor, b: Tensor, stds: Sequence[float], delta: 
     out["AbsDiffTemperatureLev"] = (bl * dT[:, :, lev]).sum() / (bl.sum() + eps)
     out["DiffVelocityNormLev"] = (bl * dv[:, :, lev]).sum() / (bl.sum() + eps)
     return out
+
+
+def weighted_lp_loss(p: Tensor, t: Tensor, b: Tensor, weight: float, power: int) -> Tensor:
+    """``WeightedL1Loss`` / ``WeightedL2Loss`` (loss_maker.py:216-255)."""
+    e = (p - t).abs() if power == 1 else (p - t) ** 2
+    m = torch.broadcast_to(b, e.shape)
+    inside = (m * e).sum() / (m.sum() + 1)
+    outside = ((1 - m) * e).sum() / ((1 - m).sum() + 1)
+    return (weight * inside + outside) / (weight + 1)
+
+
+def mixed_gradient_l2_loss(p: Tensor, t: Tensor, b: Tensor, w_g) -> Tensor:
+    """``MixedGradientL2Loss`` (loss_maker.py:258-301)."""
+    mse, grd, _ = mixed_div_grad_terms(p, t, b, 0.0 if not w_g else float(w_g), 0.0, [1.0, 1.0, 1.0])
+    return mse if not w_g else mse + w_g * grd

@@ -127,3 +127,26 @@ def test_inference_equals_oracle_on_the_reference_eval_shape_at_small_width(eng)
         pred = model(x.to(DEV), b.to(DEV))
     ref = R.unet_forward(sd, cfg["model"], x, b)
     assert relerr(pred, ref) < TOL
+
+
+@pytest.mark.parametrize("tag", ["iid", "tower"])
+def test_other_make_loss_branches(eng, tag):
+    """make_loss's WeightedL1 / WeightedL2 / MixedGradientL2Loss branches (loss_maker.py:27-38): value and dL/dp
+    against the reference's golden values"""
+    g = load_golden("metrics.npz")
+    meta = json.loads(str(g[f"{tag}/meta"]))
+    _, b, y = synthetic_inputs(meta["B"], tuple(meta["hr"]), 4, meta["seed"], meta["kind"])
+    gen = torch.Generator().manual_seed(meta["seed"] + 100)
+    p = y + 0.3 * (torch.rand(y.shape, generator=gen) - 0.5)
+    cases = {"WeightedL1": {"name": "WeightedL1", "weight_outside_building": 3.0},
+             "WeightedL2": {"name": "WeightedL2", "weight_outside_building": 0.5},
+             "MixedGradientL2": {"name": "MixedGradientL2Loss", "weight_gradient_loss": 2.0},
+             "MixedGradientL2_off": {"name": "MixedGradientL2Loss"}}
+    for nm, lc in cases.items():
+        fn = eng.make_loss({"train": {"loss": lc}, "data": {"stds": STDS}})
+        q = p.to(DEV).requires_grad_(True)
+        v = fn(q, y.to(DEV), b.to(DEV))
+        v.backward()
+        ref = float(g[f"{tag}/{nm}"])
+        assert abs(float(v.detach()) - ref) <= TOL * abs(ref), (nm, float(v.detach()), ref)
+        assert relerr(q.grad, g[f"{tag}/{nm}/dp"]) < TOL, nm
