@@ -57,6 +57,9 @@ SYMBOLS = {
     "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sr3d_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sr3d_near_wall": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sr3d_pconv_mask_update": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "sr3d_mul_mask": (_I, [_P, _P, _P, _I, _I, _LL, _I, _I, _P]),
+    "sr3d_pconv_scale": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _I, _P]),
     "sr3d_preprocess": (_I, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _I, _F, _I, _P]),
     "sr3d_loss_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_l1_fwd_bwd": (_I, [_P, _P, _LL, _P, _P, _P, _P]),

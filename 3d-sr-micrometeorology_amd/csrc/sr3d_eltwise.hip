@@ -246,6 +246,75 @@ __global__ __launch_bounds__(kThreads) void preprocess_kernel(const PrepParams q
   }
 }
 
+// ---- PartialConv3d (reference model/custom_conv.py:129-234) around the engine's convolution --------------------
+// mask statistics of every output voxel: s = sum over the (zero-padded) 3x3x3 window and the mask channels,
+// update = clamp(s, 0, 1), ratio = slide_winsize / (s + 1e-8) * update            (custom_conv.py:203-216)
+__global__ __launch_bounds__(kThreads) void pconv_mask_kernel(const float* __restrict__ m, float* __restrict__ upd,
+                                                              float* __restrict__ ratio, int Bm, int Cm, int Z, int Y,
+                                                              int X, int stride, float winsize) {
+  const int oz_ = (Z - 1) / stride + 1, oy_ = (Y - 1) / stride + 1, ox_ = (X - 1) / stride + 1;
+  const long long total = (long long)Bm * oz_ * oy_ * ox_;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int ox = (int)(r % ox_);
+    r /= ox_;
+    const int oy = (int)(r % oy_);
+    r /= oy_;
+    const int oz = (int)(r % oz_);
+    const int b = (int)(r / oz_);
+    float sacc = 0.f;
+    for (int c = 0; c < Cm; c++) {
+      const float* pm = m + ((long long)b * Cm + c) * Z * Y * X;
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            const int z = oz * stride + dz, y = oy * stride + dy, x = ox * stride + dx;
+            if ((unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)x < (unsigned)X)
+              sacc += pm[((long long)z * Y + y) * X + x];
+          }
+    }
+    const float u = fminf(fmaxf(sacc, 0.f), 1.f);
+    upd[i] = u;
+    ratio[i] = winsize / (sacc + 1e-8f) * u;
+  }
+}
+
+// out[b][c][v] = x[b][c][v] * m[b % Bm][c % Cm][v]   (mask broadcast over batch and / or channels)
+__global__ __launch_bounds__(kThreads) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                            float* __restrict__ out, int B, int C, long long vox, int Bm,
+                                                            int Cm) {
+  const long long total = (long long)B * C * vox;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long ch = i / vox, v = i - ch * vox;
+    const int b = (int)(ch / C), c = (int)(ch % C);
+    out[i] = x[i] * m[((long long)(Bm == 1 ? 0 : b) * Cm + (Cm == 1 ? 0 : c)) * vox + v];
+  }
+}
+
+// forward : out = bias ? ((raw - bias[c]) * ratio + bias[c]) * upd : raw * ratio          (custom_conv.py:224-229)
+// backward: d_raw = dy * ratio * (bias ? upd : 1);  t = dy * upd * (1 - ratio)  (its per-channel sum is d bias)
+__global__ __launch_bounds__(kThreads) void pconv_scale_kernel(const float* __restrict__ in, const float* __restrict__ bias,
+                                                               const float* __restrict__ upd, const float* __restrict__ ratio,
+                                                               float* __restrict__ out, float* __restrict__ tb, int B, int C,
+                                                               long long vox, int Bm, int has_bias, int backward) {
+  const long long total = (long long)B * C * vox;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long ch = i / vox, v = i - ch * vox;
+    const int b = (int)(ch / C), c = (int)(ch % C);
+    const long long mi = (long long)(Bm == 1 ? 0 : b) * vox + v;
+    const float u = upd[mi], rt = ratio[mi], a = in[i];
+    if (!backward) {
+      out[i] = has_bias ? ((a - bias[c]) * rt + bias[c]) * u : a * rt;
+    } else {
+      out[i] = has_bias ? a * rt * u : a * rt;
+      if (tb) tb[i] = a * u * (1.f - rt);
+    }
+  }
+}
+
 // Step bookkeeping on the DEVICE for a captured (hipGraph) training step: the host cannot advance a counter between
 // replays, so one thread increments it and derives the two bias-correction scalars exactly as the host path does
 // (double precision, then rounded to float).
@@ -394,6 +463,42 @@ int sr3d_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream, (float*)param,
                      (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, n, step_size, inv_bc2_sqrt,
                      (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)grad_scale);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_pconv_mask_update(const void* mask, int Bm, int Cm, int Z, int Y, int X, int stride, float slide_winsize,
+                           void* update_mask, void* mask_ratio, void* stream) {
+  SR3D_CHECK(mask && update_mask && mask_ratio && Bm > 0 && Cm > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG,
+             "pconv_mask_update: bad argument");
+  SR3D_CHECK(stride == 1 || stride == 2, SR3D_E_ARG, "pconv_mask_update: stride must be 1 or 2");
+  const long long total = (long long)Bm * ((Z - 1) / stride + 1) * ((Y - 1) / stride + 1) * ((X - 1) / stride + 1);
+  hipLaunchKernelGGL(pconv_mask_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)mask, (float*)update_mask, (float*)mask_ratio, Bm, Cm, Z, Y, X, stride, slide_winsize);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_mul_mask(const void* x, const void* mask, void* out, int B, int C, long long voxels, int Bm, int Cm,
+                  void* stream) {
+  SR3D_CHECK(x && mask && out && B > 0 && C > 0 && voxels > 0, SR3D_E_ARG, "mul_mask: bad argument");
+  SR3D_CHECK((Bm == 1 || Bm == B) && (Cm == 1 || Cm == C), SR3D_E_ARG, "mul_mask: mask must broadcast to the input");
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(blocks_for((long long)B * C * voxels)), dim3(kThreads), 0,
+                     (hipStream_t)stream, (const float*)x, (const float*)mask, (float*)out, B, C, voxels, Bm, Cm);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+int sr3d_pconv_scale(const void* in, const void* bias, const void* update_mask, const void* mask_ratio, void* out,
+                     void* bias_terms, int B, int C, long long voxels, int Bm, int backward, void* stream) {
+  SR3D_CHECK(in && update_mask && mask_ratio && out && B > 0 && C > 0 && voxels > 0, SR3D_E_ARG,
+             "pconv_scale: bad argument");
+  SR3D_CHECK(Bm == 1 || Bm == B, SR3D_E_ARG, "pconv_scale: mask batch must be 1 or B");
+  SR3D_CHECK(!bias_terms || (backward && bias), SR3D_E_ARG, "pconv_scale: bias_terms only in the backward of a biased conv");
+  hipLaunchKernelGGL(pconv_scale_kernel, dim3(blocks_for((long long)B * C * voxels)), dim3(kThreads), 0,
+                     (hipStream_t)stream, (const float*)in, (const float*)bias, (const float*)update_mask,
+                     (const float*)mask_ratio, (float*)out, (float*)bias_terms, B, C, voxels, Bm, bias != nullptr,
+                     backward != 0);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

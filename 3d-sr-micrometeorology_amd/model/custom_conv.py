@@ -93,3 +93,41 @@ class MyConvWithAct2(nn.Module):
         if self.conv_mode is None:
             return ops.conv3d_act(srcs, self.conv.weight, self.conv.bias, act=self._act_name, stride=self.stride)
         return self.conv.gated_forward(srcs, self._act_name)
+
+
+class PartialConv3d(nn.Conv3d):
+    """custom_conv.py:129-234 (NVIDIA partial convolution, 3-D): conv(x * mask) renormalised by the number of valid
+    inputs under each window, plus the updated mask.  Not reachable from ``UNetSR`` (no conv_mode selects it); kept as
+    an op on the engine's kernels: mask product, the fused convolution, mask statistics and renormalisation are HIP,
+    the bias is folded exactly as in the reference."""
+
+    def __init__(self, *args, **kwargs):
+        self.multi_channel = kwargs.pop("multi_channel", False)
+        self.return_mask = kwargs.pop("return_mask", False)
+        super().__init__(*args, **kwargs)
+        _check_3x3x3(self.kernel_size, self.stride[0], self.padding[0], self.dilation[0], self.groups)
+        # weight_maskUpdater is all ones: (out, in, 3,3,3) or (1, 1, 3,3,3); only its window size matters
+        self.slide_winsize = (self.in_channels if self.multi_channel else 1) * 27
+        self.last_size = (None, None, None, None, None)
+        self.update_mask = None
+        self.mask_ratio = None
+
+    def forward(self, input, mask_in=None):
+        assert len(input.shape) == 5
+        if mask_in is not None or self.last_size != tuple(input.shape):
+            self.last_size = tuple(input.shape)
+            with torch.no_grad():
+                if mask_in is None:
+                    shape = tuple(input.shape) if self.multi_channel else (1, 1) + tuple(input.shape[2:])
+                    mask = torch.ones(shape, dtype=input.dtype, device=input.device)
+                else:
+                    mask = mask_in
+                self.update_mask, self.mask_ratio = ops.pconv_mask_update(mask, self.stride[0], self.slide_winsize)
+        x = ops.MulMask.apply(input, mask_in) if mask_in is not None else input
+        raw = ops.conv3d_act([x], self.weight, self.bias, act=None, stride=self.stride[0])
+        output = ops.PconvScale.apply(raw, self.bias, self.update_mask, self.mask_ratio)
+        if self.return_mask:
+            # the reference's updated mask has one (identical) channel per output channel when multi_channel
+            um = self.update_mask
+            return output, (um.expand(-1, self.out_channels, -1, -1, -1) if self.multi_channel else um)
+        return output

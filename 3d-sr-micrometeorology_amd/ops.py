@@ -203,6 +203,68 @@ def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):
     return GatedConv3dAct.apply(w_feat, w_gate, b_feat, b_gate, act, stride, *srcs)
 
 
+# ---------------------------------------------------------------- PartialConv3d pieces
+def pconv_mask_update(mask: torch.Tensor, stride: int, slide_winsize: float):
+    """(update_mask, mask_ratio), each (Bm, 1, OZ, OY, OX) (reference custom_conv.py:203-216)"""
+    mask = mask.detach().contiguous()
+    Bm, Cm, Z, Y, X = mask.shape
+    shape = (Bm, 1, _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride))
+    upd, ratio = _empty(shape, mask), _empty(shape, mask)
+    L.check(L.lib.sr3d_pconv_mask_update(L.dev_ptr(mask), Bm, Cm, Z, Y, X, stride, float(slide_winsize), L.dev_ptr(upd),
+                                         L.dev_ptr(ratio), L.stream_ptr()), "sr3d_pconv_mask_update")
+    return upd, ratio
+
+
+class MulMask(torch.autograd.Function):
+    """x * mask with the mask broadcast over batch / channels; the mask carries no gradient"""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x, mask = x.contiguous(), mask.detach().contiguous()
+        ctx.save_for_backward(mask)
+        return MulMask._run(x, mask)
+
+    @staticmethod
+    def _run(x, mask):
+        B, c = x.shape[0], x.shape[1]
+        out = torch.empty_like(x)
+        L.check(L.lib.sr3d_mul_mask(L.dev_ptr(x), L.dev_ptr(mask), L.dev_ptr(out), B, c, x[0, 0].numel(),
+                                    int(mask.shape[0]), int(mask.shape[1]), L.stream_ptr()), "sr3d_mul_mask")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return MulMask._run(g.contiguous(), mask), None
+
+
+class PconvScale(torch.autograd.Function):
+    """the renormalisation after the convolution (custom_conv.py:224-229)"""
+
+    @staticmethod
+    def forward(ctx, raw, bias, upd, ratio):
+        raw = raw.contiguous()
+        B, c = raw.shape[0], raw.shape[1]
+        out = torch.empty_like(raw)
+        L.check(L.lib.sr3d_pconv_scale(L.dev_ptr(raw), L.dev_ptr(bias, "bias"), L.dev_ptr(upd), L.dev_ptr(ratio),
+                                       L.dev_ptr(out), None, B, c, raw[0, 0].numel(), int(upd.shape[0]), 0,
+                                       L.stream_ptr()), "sr3d_pconv_scale")
+        ctx.save_for_backward(bias, upd, ratio)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        bias, upd, ratio = ctx.saved_tensors
+        g = g.contiguous()
+        B, c = g.shape[0], g.shape[1]
+        d_raw = torch.empty_like(g)
+        terms = torch.empty_like(g) if (bias is not None and ctx.needs_input_grad[1]) else None
+        L.check(L.lib.sr3d_pconv_scale(L.dev_ptr(g), L.dev_ptr(bias, "bias"), L.dev_ptr(upd), L.dev_ptr(ratio),
+                                       L.dev_ptr(d_raw), L.dev_ptr(terms), B, c, g[0, 0].numel(), int(upd.shape[0]), 1,
+                                       L.stream_ptr()), "sr3d_pconv_scale")
+        return d_raw, (_bias_grad(terms) if terms is not None else None), None, None
+
+
 # ---------------------------------------------------------------- no-grad data movement
 def upsample_cat(x: torch.Tensor, b: torch.Tensor, scale: int) -> torch.Tensor:
     """cat[nearest_upsample(x, scale), b]  (reference unet.py:143,254-255); inputs carry no gradient."""

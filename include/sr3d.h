@@ -137,6 +137,20 @@ int sr3d_near_wall(const void* b, void* near, int B, int Z, int Y, int X, void* 
 int sr3d_preprocess(const void* x, void* out, int B, int C, int Z, int Y, int X, const float* means, const float* stds,
                     float scaling, int clip, float nan_value, int discard_z, void* stream);
 
+/* ---- PartialConv3d (model/custom_conv.py:129-234; not reachable from UNetSR, kept as an op) ---------------- */
+/* update_mask = clamp(s, 0, 1), mask_ratio = slide_winsize / (s + 1e-8) * update_mask with s = sum of the mask over the
+ * zero-padded 3x3x3 window and its Cm channels; mask: (Bm, Cm, Z, Y, X) -> both outputs (Bm, 1, OZ, OY, OX). */
+int sr3d_pconv_mask_update(const void* mask, int Bm, int Cm, int Z, int Y, int X, int stride, float slide_winsize,
+                           void* update_mask, void* mask_ratio, void* stream);
+/* out = x * mask, the mask broadcast over batch (Bm = 1) and / or channels (Cm = 1) */
+int sr3d_mul_mask(const void* x, const void* mask, void* out, int B, int C, long long voxels, int Bm, int Cm,
+                  void* stream);
+/* forward (backward = 0): out = bias ? ((in - bias[c]) * ratio + bias[c]) * update : in * ratio
+ * backward (= 1): out = in * ratio * (bias ? update : 1); bias_terms (optional) = in * update * (1 - ratio), whose
+ * per-channel sum (sr3d_bias_grad) is the bias gradient */
+int sr3d_pconv_scale(const void* in, const void* bias, const void* update_mask, const void* mask_ratio, void* out,
+                     void* bias_terms, int B, int C, long long voxels, int Bm, int backward, void* stream);
+
 /* ---- losses (forward value + dL/dp in one pass) --------------------------- */
 /* out[0] = mean|p-t| ; dLdp = sign(p-t)/n * grad_scale           MyL1Loss, loss_maker.py:194-202 */
 size_t sr3d_loss_workspace_bytes(int B, int Z, int Y, int X);

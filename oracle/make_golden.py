@@ -376,7 +376,40 @@ def metrics_fixture():
     print("metrics.npz", len(out))
 
 
+
+def pconv_fixture():
+    """PartialConv3d (custom_conv.py:129-234): forward, updated mask and all gradients"""
+    out = {}
+    cases = {"multi_bias": dict(cin=3, cout=4, stride=1, bias=True, multi=True, mask="given"),
+             "single_nobias_s2": dict(cin=5, cout=6, stride=2, bias=False, multi=False, mask="given"),
+             "single_bias_nomask": dict(cin=2, cout=3, stride=1, bias=True, multi=False, mask=None)}
+    for name, c in cases.items():
+        torch.manual_seed(17)
+        pc = PartialConv3d(c["cin"], c["cout"], 3, stride=c["stride"], padding=1, bias=c["bias"],
+                           multi_channel=c["multi"], return_mask=True)
+        g = torch.Generator().manual_seed(18)
+        x = (torch.rand(2, c["cin"], 6, 7, 9, generator=g) - 0.5).requires_grad_(True)
+        mk = None
+        if c["mask"] == "given":
+            mk = (torch.rand(2, c["cin"] if c["multi"] else 1, 6, 7, 9, generator=g) > 0.4).float()
+        y, um = pc(x, mk)
+        gy = torch.rand(y.shape, generator=g) - 0.5
+        y.backward(gy)
+        out[f"{name}/meta"] = np.array(json.dumps(c))
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/um"], out[f"{name}/gy"] = npy(x), npy(y), npy(um), npy(gy)
+        if mk is not None:
+            out[f"{name}/mask"] = npy(mk)
+        out[f"{name}/gx"], out[f"{name}/w"], out[f"{name}/gw"] = npy(x.grad), npy(pc.weight), npy(pc.weight.grad)
+        if c["bias"]:
+            out[f"{name}/b"], out[f"{name}/gb"] = npy(pc.bias), npy(pc.bias.grad)
+    np.savez_compressed(os.path.join(OUT, "pconv.npz"), **out)
+    print("pconv.npz", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pconv":
+        pconv_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         metrics_fixture()
         sys.exit(0)

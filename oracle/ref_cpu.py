@@ -322,17 +322,22 @@ def make_loss(config: dict):
 # --------------------------------------------------------------------------
 # PartialConv3d (dead code in the reference; custom_conv.py:129-234)
 # --------------------------------------------------------------------------
-def partial_conv3d(x: Tensor, mask: Tensor, weight: Tensor, bias: Optional[Tensor],
-                   stride: int = 1, padding: int = 1) -> Tuple[Tensor, Tensor]:
-    """multi_channel=True, return_mask=True form of ``PartialConv3d.forward``
-    (custom_conv.py:176-234)."""
-    ones = torch.ones_like(weight)
-    upd = F.conv3d(mask, ones, None, stride=stride, padding=padding)
-    win = weight.shape[1] * weight.shape[2] * weight.shape[3] * weight.shape[4]
+def partial_conv3d(x: Tensor, mask: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
+                   stride: int = 1, padding: int = 1, multi_channel: bool = True) -> Tuple[Tensor, Tensor]:
+    """``PartialConv3d.forward`` with ``return_mask=True`` (custom_conv.py:176-234).  ``mask`` None = the all-ones
+    mask the reference builds itself (:188-199); single-channel masks use the (1, 1, 3, 3, 3) updater."""
+    if multi_channel:
+        ones = torch.ones_like(weight)
+        given = mask if mask is not None else torch.ones_like(x)
+    else:
+        ones = torch.ones(1, 1, *weight.shape[2:], dtype=weight.dtype)
+        given = mask if mask is not None else torch.ones(1, 1, *x.shape[2:], dtype=x.dtype)
+    upd = F.conv3d(given, ones, None, stride=stride, padding=padding)
+    win = ones.shape[1] * ones.shape[2] * ones.shape[3] * ones.shape[4]
     ratio = win / (upd + 1e-8)
     upd = upd.clamp(0, 1)
     ratio = ratio * upd
-    raw = F.conv3d(x * mask, weight, bias, stride=stride, padding=padding)
+    raw = F.conv3d(x * mask if mask is not None else x, weight, bias, stride=stride, padding=padding)
     if bias is not None:
         bv = bias.view(1, -1, 1, 1, 1)
         out = ((raw - bv) * ratio + bv) * upd

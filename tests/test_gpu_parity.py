@@ -288,3 +288,37 @@ def test_gated_conv_with_two_output_channels(eng):
     assert relerr(xd.grad, x.grad) < TOL
     assert relerr(wfd.grad, wf.grad) < TOL_G and relerr(wgd.grad, wg.grad) < TOL_G
     assert relerr(bgd.grad, bg.grad) < TOL_G
+
+
+@pytest.mark.parametrize("name", ["multi_bias", "single_nobias_s2", "single_bias_nomask"])
+def test_partial_conv3d_vs_reference(eng, name):
+    """PartialConv3d (custom_conv.py:129-234) on the engine: forward, updated mask, input / weight / bias gradients"""
+    g = load_golden("pconv.npz")
+    c = json.loads(str(g[f"{name}/meta"]))
+    pc = eng.model.custom_conv.PartialConv3d(c["cin"], c["cout"], 3, stride=c["stride"], padding=1, bias=c["bias"],
+                                             multi_channel=c["multi"], return_mask=True)
+    with torch.no_grad():
+        pc.weight.copy_(T(g[f"{name}/w"]))
+        if c["bias"]:
+            pc.bias.copy_(T(g[f"{name}/b"]))
+    pc.to(DEV)
+    x = T(g[f"{name}/x"]).to(DEV).requires_grad_(True)
+    mk = T(g[f"{name}/mask"]).to(DEV) if f"{name}/mask" in g else None
+    y, um = pc(x, mk)
+    assert relerr(y, g[f"{name}/y"]) < TOL
+    assert torch.equal(um.cpu(), T(g[f"{name}/um"]))
+    y.backward(T(g[f"{name}/gy"]).to(DEV))
+    assert relerr(x.grad, g[f"{name}/gx"]) < TOL
+    assert relerr(pc.weight.grad, g[f"{name}/gw"]) < TOL_G
+    if c["bias"]:
+        assert relerr(pc.bias.grad, g[f"{name}/gb"]) < TOL_G
+    # the ops.npz fixture of round 1 (multi-channel, forward only)
+    if name == "multi_bias":
+        o = load_golden("ops.npz")
+        pc2 = eng.model.custom_conv.PartialConv3d(3, 4, 3, padding=1, multi_channel=True, return_mask=True)
+        with torch.no_grad():
+            pc2.weight.copy_(T(o["pconv/weight"]))
+            pc2.bias.copy_(T(o["pconv/bias"]))
+        pc2.to(DEV)
+        y2, m2 = pc2(T(o["pconv/x"]).to(DEV), T(o["pconv/mask"]).to(DEV))
+        assert relerr(y2, o["pconv/y"]) < TOL and torch.equal(m2.cpu(), T(o["pconv/mask_out"]))
