@@ -7,6 +7,7 @@ backward -- nothing here falls back to ATen convolution.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -19,6 +20,42 @@ from . import _lib as L
 # (oracle/ref_cpu.py:_act), which removes the only non-smooth step from a whole-model comparison.  Never set in
 # production code: it costs a device-to-host copy per layer.
 KINK_LOG: Optional[list] = None
+
+
+# Weight gradient and input gradient of one layer only share their inputs: on the small grids of U-Net levels 2-4 (a few
+# dozen to a few hundred workgroups per kernel, fewer than the 256 CUs) they are launched on two HIP streams so that
+# together they fill the chip; on the large grids every kernel fills it alone and a second stream buys nothing.
+_SIDE_STREAMS: dict = {}
+CONCURRENT_WGRAD_MAX_VOXELS = int(os.environ.get("SR3D_CONCURRENT_WGRAD_MAX_VOXELS", str(1_100_000)))   # levels >= 1 of the 80x320x320 benchmark grid
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
+def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of):
+    """(dxs, dw, [bias grads]) with the weight-side work on a side stream when the layer's grid is small"""
+    vox = desc.Z * desc.Y * desc.X * desc.B
+    if not want_w or not any(needs) or vox > CONCURRENT_WGRAD_MAX_VOXELS:
+        dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
+        dw = _bwd_weight(desc, srcs, dys) if want_w else None
+        return dxs, dw, [_bias_grad(t) if t is not None else None for t in bias_of]
+    cur = torch.cuda.current_stream(dys[0].device)
+    side = _side_stream(dys[0].device)
+    side.wait_stream(cur)                      # dys / srcs were produced on the current stream
+    with torch.cuda.stream(side):
+        dw = _bwd_weight(desc, srcs, dys)
+        dbs = [_bias_grad(t) if t is not None else None for t in bias_of]
+    dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
+    cur.wait_stream(side)                      # join: everything returned is ready in current-stream order
+    for t in [dw] + dbs:
+        if t is not None:
+            t.record_stream(cur)
+    return dxs, dw, dbs
 
 
 def _out_dim(z: int, s: int) -> int:
@@ -138,9 +175,9 @@ class Conv3dAct(torch.autograd.Function):
         else:
             raise NotImplementedError(f"backward of plain conv with act={ctx.act}")
         needs = ctx.needs_input_grad[5:5 + ctx.nsrc]
-        dxs = _bwd_data(desc, srcs, needs, [dpre], weight, None)
-        dw = _bwd_weight(desc, srcs, [dpre]) if ctx.needs_input_grad[0] else None
-        db = _bias_grad(dpre) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        dxs, dw, (db,) = _grads_two_streams(desc, srcs, needs, [dpre], weight, None, ctx.needs_input_grad[0],
+                                            [dpre if want_b else None])
         return (dw, db, None, None, None, *dxs)
 
 
@@ -185,13 +222,11 @@ class GatedConv3dAct(torch.autograd.Function):
                                          L.dev_ptr(d_gate), dy.numel(), L.ACT_CODE[ctx.act], L.stream_ptr()),
                 "sr3d_gated_act_bwd")
         needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
-        dxs = _bwd_data(desc, srcs, needs, [d_feat, d_gate], w_feat, w_gate)
-        dwf = dwg = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dw = _bwd_weight(desc, srcs, [d_feat, d_gate])
-            dwf, dwg = dw[:desc.Cout], dw[desc.Cout:]
-        dbf = _bias_grad(d_feat) if (ctx.has_bf and ctx.needs_input_grad[2]) else None
-        dbg = _bias_grad(d_gate) if ctx.needs_input_grad[3] else None
+        want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dxs, dw, (dbf, dbg) = _grads_two_streams(
+            desc, srcs, needs, [d_feat, d_gate], w_feat, w_gate, want_w,
+            [d_feat if (ctx.has_bf and ctx.needs_input_grad[2]) else None, d_gate if ctx.needs_input_grad[3] else None])
+        dwf, dwg = (dw[:desc.Cout], dw[desc.Cout:]) if dw is not None else (None, None)
         return (dwf, dwg, dbf, dbg, None, None, *dxs)
 
 
