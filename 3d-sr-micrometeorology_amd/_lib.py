@@ -90,6 +90,16 @@ def _load():
 lib = _load()
 
 
+PROFILING = False   # per-kernel HIP-event timing is on (bench.py): ops then keeps every launch on ONE stream
+
+
+def profile_enable(on: bool) -> None:
+    """sr3d_profile_enable + the flag `ops` reads: kernels overlapped on two streams cannot be timed one by one"""
+    global PROFILING
+    check(lib.sr3d_profile_enable(1 if on else 0), "sr3d_profile_enable")
+    PROFILING = bool(on)
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise RuntimeError(f"{what} failed (code {rc}): {lib.sr3d_last_error().decode()}")

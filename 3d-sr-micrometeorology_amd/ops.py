@@ -40,7 +40,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of):
     """(dxs, dw, [bias grads]) with the weight-side work on a side stream when the layer's grid is small"""
     vox = desc.Z * desc.Y * desc.X * desc.B
-    if not want_w or not any(needs) or vox > CONCURRENT_WGRAD_MAX_VOXELS:
+    if not want_w or not any(needs) or vox > CONCURRENT_WGRAD_MAX_VOXELS or L.PROFILING:
         dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
         dw = _bwd_weight(desc, srcs, dys) if want_w else None
         return dxs, dw, [_bias_grad(t) if t is not None else None for t in bias_of]
