@@ -133,6 +133,24 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
     dist.destroy_process_group()
 
 
+def write_out_inferences(*, test_loader, model, inference_dir: str, device: str) -> None:
+    """train_model.py:83-101: one forward pass per test sample (whole domain), saved next to its inputs as
+    <time stamp>_{LR,BM,HR,SR}.npy in normalised units, with the sample's L1 error in the log"""
+    import sr3d_amd
+    l1 = sr3d_amd.make_loss({"train": {"loss": {"name": "L1"}}})
+    os.makedirs(inference_dir, exist_ok=True)
+    for hr_path, (Xs, bs, ys) in zip(test_loader.dataset.hr_files, test_loader):
+        bs = bs.unsqueeze(1)
+        with torch.no_grad():
+            Xd, bd, yd = Xs.to(device), bs.to(device), ys.to(device)
+            preds = model(Xd, bd)
+            err = float(l1(preds, yd, bd))
+        stamp = os.path.basename(hr_path).split("_")[0]
+        for label, t in (("LR", Xs), ("BM", bs), ("HR", ys), ("SR", preds.cpu())):
+            np.save(os.path.join(inference_dir, f"{stamp}_{label}.npy"), t.numpy())
+        logger.info(f"{stamp}, l1 = {err:.7f}")
+
+
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -147,6 +165,7 @@ def main():
     ap.add_argument("--world_size", type=int, default=2)
     ap.add_argument("--data_root", type=str, default=f"{ROOT}/data/DL_data")
     ap.add_argument("--result_root", type=str, default=f"{ROOT}/data/DL_results")
+    ap.add_argument("--inference_root", type=str, default=f"{ROOT}/data/DL_inferences")
     args = ap.parse_args()
 
     with open(args.config_path) as f:
@@ -198,6 +217,9 @@ def main():
             "DiffOmegaVectorNorm": lm.DiffOmegaVectorNorm(stds[1:]),
         }
         results = evaluate(dataloader=test_loader, model=model, loss_fns=loss_fns, device="cuda:0")
+        if config["train"].get("write_out_inferences", False):        # train_model.py:391-397
+            write_out_inferences(test_loader=test_loader, model=model, device="cuda:0",
+                                 inference_dir=f"{args.inference_root}/{experiment_name}/{config_name}")
         for k, v in results.items():
             logger.info(f"{k}: {v.avg:.8f}")
             if mlflow is not None:

@@ -22,6 +22,7 @@ def test_train_script_single_gpu(tmp_path):
                  "datasizes": {"train": 100, "valid": 100, "test": 100}, "nan_value": 0.0, "batch_size": 2, "seed": 42,
                  "num_workers": 0},
         "train": {"num_epochs": 2, "lr": 1.0e-3, "num_loops_train": 1, "num_loops_valid": 1, "seed": 42,
+                  "write_out_inferences": True,
                   "loss": {"name": "MixedDivergenceGradientL2Loss", "weight_gradient_loss": 1.0,
                            "weight_divergence_loss": 10.0},
                   "grad_norm": {"n_tasks": 3, "alpha": 1.5, "lr": 1.0e-2}},
@@ -36,7 +37,8 @@ def test_train_script_single_gpu(tmp_path):
     cfg_path.write_text(yaml.safe_dump(cfg))
     script = os.path.join(ROOT, "3d-sr-micrometeorology_amd", "script", "train_model.py")
     r = subprocess.run([sys.executable, script, "--config_path", str(cfg_path), "--world_size", "1", "--data_root",
-                        str(data_root), "--result_root", str(tmp_path / "res")], capture_output=True, text=True,
+                        str(data_root), "--result_root", str(tmp_path / "res"), "--inference_root",
+                        str(tmp_path / "inf")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = tmp_path / "res" / "exp" / "tiny"
@@ -46,3 +48,15 @@ def test_train_script_single_gpu(tmp_path):
     assert hist[0] == "loss,val_loss" and len(hist) == 3
     assert "Epoch: 2" in (out / "log.txt").read_text()
     assert (out / "grad_norm_weights_0.csv").exists()
+    # final evaluation: the reference's ten metrics on the whole-domain test loader, then the inferences
+    log = (out / "log.txt").read_text()
+    for name in ("L1", "MaskedL1", "MaskedL1NearWall", "ResidualContinuityEq", "AbsDiffTemperature", "DiffVelocityNorm",
+                 "AbsDiffTemperatureLevZero", "DiffVelocityNormLevZero", "AbsDiffDivergence", "DiffOmegaVectorNorm"):
+        assert f"{name}: " in log, name
+    import numpy as np
+    inf = sorted(os.listdir(tmp_path / "inf" / "exp" / "tiny"))
+    assert len(inf) % 4 == 0 and len(inf) >= 4 and inf[0].endswith("_BM.npy")
+    stamp = inf[0].split("_")[0]
+    sr = np.load(tmp_path / "inf" / "exp" / "tiny" / f"{stamp}_SR.npy")
+    hr = np.load(tmp_path / "inf" / "exp" / "tiny" / f"{stamp}_HR.npy")
+    assert sr.shape == hr.shape == (1, 4, 16, 32, 32) and np.isfinite(sr).all()
