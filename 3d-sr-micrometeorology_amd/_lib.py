@@ -68,6 +68,8 @@ SYMBOLS = {
     "sr3d_weighted_lp_bwd": (_I, [_P, _P, _P, _I, _I, _LL, _I, _P, _P, _P]),
     "sr3d_eval_metrics_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sr3d_eval_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.POINTER(_F), _F, _I, _P, _P, _P]),
+    "sr3d_ssim3d_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "sr3d_ssim3d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _I, _F, _F, _P, _P, _P, _P]),
     "sr3d_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _I, _D, _P]),
     "sr3d_adam_step_device_counter": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _P, _P, _D, _P]),
     "sr3d_profile_enable": (_I, [_I]),

@@ -380,6 +380,92 @@ __global__ __launch_bounds__(kThreads) void weighted_lp_bwd_kernel(const float* 
   }
 }
 
+// ---------------------------------------------------------------- SSIM3D (reference src/ssim.py:52-115)
+// The reference filters six fields (x1 m, x2 m, m, (x1 m)^2, (x2 m)^2, x1 x2 m^2) with a dense w x w x w window
+// (1331 taps at the default size 11).  The window is an outer product, so three 1-D passes do the same: x (fused with
+// forming the six fields), y, and z (fused with the SSIM formula and the mean).
+constexpr int kSsimMaxTaps = 15;
+struct SsimParams {
+  const float* a;      // img1 (B, C, Z, Y, X)
+  const float* b;      // img2
+  const float* m;      // mask (B, Cm, Z, Y, X), Cm = 1 or C
+  float* f0;           // 6 fields after the x pass   [6][B*C*vox]
+  float* f1;           // 6 fields after the y pass
+  float* map;          // optional ssim map
+  float* part;         // per-block partial sums
+  int B, C, Cm, Z, Y, X, n;
+  float w[kSsimMaxTaps];
+  float c1, c2, eps;
+  long long total;     // B * C * Z * Y * X
+};
+
+__global__ __launch_bounds__(kThreads) void ssim_x_kernel(const SsimParams q) {
+  const int r = q.n / 2;
+  const long long vox = (long long)q.Z * q.Y * q.X;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q.total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % q.X);
+    const long long ch = i / vox;                       // b * C + c
+    const long long mrow = (q.Cm == 1 ? (ch / q.C) : ch) * vox + (i - ch * vox) - x;
+    const long long row = i - x;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < q.n; k++) {
+      const int xx = x + k - r;
+      if ((unsigned)xx >= (unsigned)q.X) continue;
+      const float mv = q.m[mrow + xx];
+      const float u = q.a[row + xx] * mv, v = q.b[row + xx] * mv, wk = q.w[k];
+      s[0] += wk * u, s[1] += wk * v, s[2] += wk * mv, s[3] += wk * (u * u), s[4] += wk * (v * v), s[5] += wk * (u * v);
+    }
+#pragma unroll
+    for (int f = 0; f < 6; f++) q.f0[f * q.total + i] = s[f];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ssim_y_kernel(const SsimParams q) {
+  const int r = q.n / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q.total; i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)((i / q.X) % q.Y);
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < q.n; k++) {
+      const int yy = y + k - r;
+      if ((unsigned)yy >= (unsigned)q.Y) continue;
+      const long long o = i + (long long)(yy - y) * q.X;
+      const float wk = q.w[k];
+#pragma unroll
+      for (int f = 0; f < 6; f++) s[f] += wk * q.f0[f * q.total + o];
+    }
+#pragma unroll
+    for (int f = 0; f < 6; f++) q.f1[f * q.total + i] = s[f];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ssim_z_kernel(const SsimParams q) {
+  __shared__ float red[4];
+  const int r = q.n / 2;
+  const long long yx = (long long)q.Y * q.X;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q.total; i += (long long)gridDim.x * blockDim.x) {
+    const int z = (int)((i / yx) % q.Z);
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < q.n; k++) {
+      const int zz = z + k - r;
+      if ((unsigned)zz >= (unsigned)q.Z) continue;
+      const long long o = i + (long long)(zz - z) * yx;
+      const float wk = q.w[k];
+#pragma unroll
+      for (int f = 0; f < 6; f++) s[f] += wk * q.f1[f * q.total + o];
+    }
+    const float wt = s[2] + q.eps;
+    const float mu1 = s[0] / wt, mu2 = s[1] / wt;
+    const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = s[3] / wt - mu1s, s2 = s[4] / wt - mu2s, s12 = s[5] / wt - mu12;
+    const float v = ((2.f * mu12 + q.c1) * (2.f * s12 + q.c2)) / ((mu1s + mu2s + q.c1) * (s1 + s2 + q.c2));
+    if (q.map) q.map[i] = v;
+    acc += v;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) q.part[blockIdx.x] = tot;
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,6 +540,39 @@ int sr3d_weighted_lp_bwd(const void* p, const void* t, const void* b, int B, int
   hipLaunchKernelGGL(weighted_lp_bwd_kernel, dim3(grid_for(total, 1)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)p, (const float*)t, (const float*)b, total, voxels, C, power, (const float*)coef,
                      (float*)dLdp);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+size_t sr3d_ssim3d_workspace_bytes(int B, int C, int Z, int Y, int X) {
+  return ((size_t)12 * B * C * Z * Y * X + kMaxBlocks) * sizeof(float);
+}
+
+int sr3d_ssim3d(const void* img1, const void* img2, const void* mask, int B, int C, int Cm, int Z, int Y, int X,
+                const float* window, int n, float max_val, float eps, void* mean_out, void* ssim_map, void* workspace,
+                void* stream) {
+  SR3D_CHECK(img1 && img2 && mask && window && mean_out && workspace, SR3D_E_ARG, "ssim3d: null pointer");
+  SR3D_CHECK(B > 0 && C > 0 && Z > 0 && Y > 0 && X > 0 && (Cm == 1 || Cm == C), SR3D_E_ARG, "ssim3d: bad shape");
+  SR3D_CHECK(n >= 1 && n <= kSsimMaxTaps && (n & 1), SR3D_E_ARG, "ssim3d: window size must be odd and <= %d", kSsimMaxTaps);
+  SsimParams q{};
+  q.a = (const float*)img1, q.b = (const float*)img2, q.m = (const float*)mask;
+  q.B = B, q.C = C, q.Cm = Cm, q.Z = Z, q.Y = Y, q.X = X, q.n = n;
+  for (int k = 0; k < n; k++) q.w[k] = window[k];
+  q.c1 = (max_val * 0.01f) * (max_val * 0.01f), q.c2 = (max_val * 0.03f) * (max_val * 0.03f), q.eps = eps;
+  q.total = (long long)B * C * Z * Y * X;
+  float* ws = (float*)workspace;
+  q.f0 = ws, q.f1 = ws + 6 * q.total, q.part = ws + 12 * q.total, q.map = (float*)ssim_map;
+  const int nb = grid_for(q.total, 1);
+  hipStream_t st = (hipStream_t)stream;
+  SrProfScope prof(SR3D_PROF_EVAL, (12.0 + 4.0 * Cm / C + 4.0) * (double)q.total, st);
+  hipLaunchKernelGGL(ssim_x_kernel, dim3(nb), dim3(kThreads), 0, st, q);
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ssim_y_kernel, dim3(nb), dim3(kThreads), 0, st, q);
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ssim_z_kernel, dim3(nb), dim3(kThreads), 0, st, q);
+  SR3D_HIP(hipGetLastError());
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(kThreads), 0, st, (const float*)q.part, nb, (float*)mean_out,
+                     1.0 / (double)q.total);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

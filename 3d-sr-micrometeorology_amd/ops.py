@@ -454,6 +454,27 @@ def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequen
     return out
 
 
+def ssim3d(img1: torch.Tensor, img2: torch.Tensor, mask: torch.Tensor, window: Sequence[float], max_val: float = 1.0,
+           eps: float = 1e-7, size_average: bool = True) -> torch.Tensor:
+    """masked SSIM3D of the reference (src/ssim.py:52-115) as three separable HIP passes; forward only.
+    ``window``: the 1-D taps whose triple outer product is the reference's window."""
+    if torch.is_grad_enabled() and (img1.requires_grad or img2.requires_grad):
+        raise NotImplementedError("ssim3d is an evaluation metric on this engine: call it under torch.no_grad()")
+    img1, img2, mask = img1.detach().contiguous(), img2.detach().contiguous(), mask.detach().contiguous()
+    B, c, Z, Y, X = img1.shape
+    if img2.shape != img1.shape or mask.shape[0] != B or tuple(mask.shape[2:]) != (Z, Y, X) or mask.shape[1] not in (1, c):
+        raise ValueError("ssim3d: img1, img2 (B,C,Z,Y,X) and a mask with 1 or C channels on the same grid")
+    n = len(window)
+    ws = torch.empty(L.lib.sr3d_ssim3d_workspace_bytes(B, c, Z, Y, X) // 4, dtype=torch.float32, device=img1.device)
+    mean = _empty((1,), img1)
+    smap = None if size_average else torch.empty_like(img1)
+    taps = (C.c_float * n)(*[float(v) for v in window])
+    L.check(L.lib.sr3d_ssim3d(L.dev_ptr(img1), L.dev_ptr(img2), L.dev_ptr(mask), B, c, int(mask.shape[1]), Z, Y, X, taps,
+                              n, float(max_val), float(eps), L.dev_ptr(mean), L.dev_ptr(smap), L.dev_ptr(ws),
+                              L.stream_ptr()), "sr3d_ssim3d")
+    return mean[0] if size_average else smap
+
+
 class WeightedLpFn(torch.autograd.Function):
     """WeightedL1Loss / WeightedL2Loss (reference loss_maker.py:216-255):
     (w * sum_in(e) / (N_in + 1) + sum_out(e) / (N_out + 1)) / (w + 1) with e = |p - t| or (p - t)^2, `in` = mask 1

@@ -286,6 +286,25 @@ class MixedDivergenceGradientL2LossDivMse(_MixedTerm):
     term, wg, wd = 2, 0.0, 1.0
 
 
+class Ssim3dLoss(nn.Module):
+    """loss_maker.py:748-777 (note its default eps = 1e-3, unlike SSIM3D's 1e-7)"""
+
+    def __init__(self, window_size: int = 11, sigma: float = 1.5, size_average: bool = True, max_val: float = 1.0,
+                 eps: float = 1e-3, use_gaussian=True):
+        super().__init__()
+        from .ssim import SSIM3D
+        self.ssim = SSIM3D(window_size=window_size, sigma=sigma, size_average=size_average, max_val=max_val, eps=eps,
+                           use_gaussian=use_gaussian)
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        assert predicts.shape == targets.shape
+        # the reference broadcasts the mask to the prediction's shape; the kernel reads the 1-channel mask directly
+        from .ssim import _taps
+        m = self.ssim
+        return ops.ssim3d(predicts, targets, masks, _taps(m.window_size, m.sigma, m.use_gaussian), m.max_val, m.eps,
+                          m.size_average)
+
+
 def merged_metric_scales(loss_fns) -> typing.Tuple[typing.Optional[float], ...]:
     """union of the scales the fused metrics in ``loss_fns`` depend on (None where nobody cares or they disagree)"""
     merged: typing.List[typing.Optional[float]] = [None] * 4

@@ -206,6 +206,15 @@ size_t sr3d_eval_metrics_workspace_bytes(int B, int Z, int Y, int X);
 int sr3d_eval_metrics(const void* p, const void* t, const void* b, int B, int Z, int Y, int X, const float stds[4],
                       float delta_meter, int lev, void* out, void* workspace, void* stream);
 
+/* SSIM3D (reference src/ssim.py:52-115: masked structural similarity with a w x w x w Gaussian or uniform window,
+ * zero padding).  img1, img2: (B, C, Z, Y, X); mask: (B, Cm, Z, Y, X) with Cm = 1 or C; `window`: the n 1-D taps
+ * (HOST array, n odd, <= 15) whose triple outer product is the reference's 3-D window; mean_out: 1 float (device) =
+ * mean of the SSIM map; ssim_map (optional): the map itself (size_average = False). */
+size_t sr3d_ssim3d_workspace_bytes(int B, int C, int Z, int Y, int X);
+int sr3d_ssim3d(const void* img1, const void* img2, const void* mask, int B, int C, int Cm, int Z, int Y, int X,
+                const float* window, int n, float max_val, float eps, void* mean_out, void* ssim_map, void* workspace,
+                void* stream);
+
 /* ---- optimizer -------------------------------------------------------------- */
 /* torch.optim.Adam defaults (train_model.py:183) on one flat fp32 buffer; step is 1-based.  The
  * hyper-parameters are doubles, as in torch (1 - beta2 must be formed in double to match it). */

@@ -406,7 +406,32 @@ def pconv_fixture():
     print("pconv.npz", len(out))
 
 
+
+def ssim_fixture():
+    """the reference's SSIM3D / Ssim3dLoss (src/ssim.py, loss_maker.py:748-777) on a seeded small input"""
+    from src import loss_maker as LM
+    from src.ssim import SSIM3D, ssim3D
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_inputs
+    _, b, y = synthetic_inputs(2, (12, 20, 24), 4, 61, "iid")
+    g = torch.Generator().manual_seed(62)
+    p = (y + 0.2 * (torch.rand(y.shape, generator=g) - 0.5)).clamp(0, 1)
+    m4 = torch.broadcast_to(b, p.shape).contiguous()
+    out = {"meta": np.array(json.dumps(dict(B=2, hr=(12, 20, 24), seed=61)))}
+    out["gauss11_mean"] = np.array(float(SSIM3D()(p, y, m4)), dtype=np.float64)
+    out["gauss11_map"] = npy(SSIM3D(size_average=False)(p, y, m4))
+    out["uniform7_mean"] = np.array(float(SSIM3D(window_size=7, use_gaussian=False)(p, y, m4)), dtype=np.float64)
+    out["gauss5_s08_max2_mean"] = np.array(float(SSIM3D(window_size=5, sigma=0.8, max_val=2.0)(p, y, m4)), dtype=np.float64)
+    out["fn_mean"] = np.array(float(ssim3D(p, y, m4)), dtype=np.float64)
+    out["loss_mean"] = np.array(float(LM.Ssim3dLoss()(p, y, b)), dtype=np.float64)        # eps = 1e-3
+    np.savez_compressed(os.path.join(OUT, "ssim.npz"), **out)
+    print("ssim.npz", {k: float(v) for k, v in out.items() if k.endswith("mean")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ssim":
+        ssim_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pconv":
         pconv_fixture()
         sys.exit(0)

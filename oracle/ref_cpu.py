@@ -538,3 +538,28 @@ def mixed_gradient_l2_loss(p: Tensor, t: Tensor, b: Tensor, w_g) -> Tensor:
     """``MixedGradientL2Loss`` (loss_maker.py:258-301)."""
     mse, grd, _ = mixed_div_grad_terms(p, t, b, 0.0 if not w_g else float(w_g), 0.0, [1.0, 1.0, 1.0])
     return mse if not w_g else mse + w_g * grd
+
+
+def ssim3d(img1: Tensor, img2: Tensor, mask: Tensor, window_size: int = 11, sigma: float = 1.5, max_val: float = 1.0,
+           eps: float = 1e-7, use_gaussian: bool = True, size_average: bool = True) -> Tensor:
+    """``_ssim_3D`` (src/ssim.py:52-115) with its dense depthwise w x w x w window; mask already of img1's shape."""
+    if use_gaussian:
+        w = torch.tensor([math.exp(-((i - window_size // 2) ** 2) / float(2 * sigma ** 2)) for i in range(window_size)])
+    else:
+        w = torch.ones(window_size)
+    w = (w / w.sum()).unsqueeze(1)
+    w3 = w.mm(w.mm(w.t()).reshape(1, -1)).reshape(window_size, window_size, window_size).float()
+    C = img1.shape[1]
+    win = w3[None, None].expand(C, 1, -1, -1, -1).contiguous().to(img1.dtype)
+
+    def filt(t):
+        return F.conv3d(t, win, padding=window_size // 2, groups=C)
+    a, b = img1 * mask, img2 * mask
+    wt = filt(mask) + eps
+    mu1, mu2 = filt(a) / wt, filt(b) / wt
+    s1 = filt(a * a) / wt - mu1.pow(2)
+    s2 = filt(b * b) / wt - mu2.pow(2)
+    s12 = filt(a * b) / wt - mu1 * mu2
+    c1, c2 = (max_val * 0.01) ** 2, (max_val * 0.03) ** 2
+    smap = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1.pow(2) + mu2.pow(2) + c1) * (s1 + s2 + c2))
+    return smap.mean() if size_average else smap

@@ -150,3 +150,30 @@ def test_other_make_loss_branches(eng, tag):
         ref = float(g[f"{tag}/{nm}"])
         assert abs(float(v.detach()) - ref) <= TOL * abs(ref), (nm, float(v.detach()), ref)
         assert relerr(q.grad, g[f"{tag}/{nm}/dp"]) < TOL, nm
+
+
+def test_ssim3d_vs_reference(eng):
+    """SSIM3D / ssim3D / Ssim3dLoss (src/ssim.py, loss_maker.py:748-777) from the separable three-pass kernel"""
+    from sr3d_amd.src.ssim import SSIM3D, ssim3D
+    g = load_golden("ssim.npz")
+    _, b, y = synthetic_inputs(2, (12, 20, 24), 4, 61, "iid")
+    gen = torch.Generator().manual_seed(62)
+    p = (y + 0.2 * (torch.rand(y.shape, generator=gen) - 0.5)).clamp(0, 1)
+    pd, yd, bd = p.to(DEV), y.to(DEV), b.to(DEV)
+    m4 = torch.broadcast_to(bd, pd.shape).contiguous()
+    with torch.no_grad():
+        assert abs(float(SSIM3D()(pd, yd, m4)) - float(g["gauss11_mean"])) < TOL
+        assert relerr(SSIM3D(size_average=False)(pd, yd, m4), g["gauss11_map"]) < TOL
+        assert abs(float(SSIM3D(window_size=7, use_gaussian=False)(pd, yd, m4)) - float(g["uniform7_mean"])) < TOL
+        assert abs(float(SSIM3D(window_size=5, sigma=0.8, max_val=2.0)(pd, yd, m4)) - float(g["gauss5_s08_max2_mean"])) < TOL
+        assert abs(float(ssim3D(pd, yd, m4)) - float(g["fn_mean"])) < TOL
+        assert abs(float(eng.src.loss_maker.Ssim3dLoss()(pd, yd, bd)) - float(g["loss_mean"])) < TOL
+    with pytest.raises(NotImplementedError):
+        SSIM3D()(pd.clone().requires_grad_(True), yd, m4)
+    # the reference's evaluation shape against the oracle (dense 1331-tap window on the CPU: crop to keep it short)
+    x2, b2, y2 = synthetic_inputs(1, (16, 48, 64), 4, 63, "tower")
+    p2 = (y2 + 0.1).clamp(0, 1)
+    with torch.no_grad():
+        got = float(eng.src.loss_maker.Ssim3dLoss()(p2.to(DEV), y2.to(DEV), b2.to(DEV)))
+    ref = float(R.ssim3d(p2, y2, torch.broadcast_to(b2, p2.shape).contiguous(), eps=1e-3))
+    assert abs(got - ref) < TOL
