@@ -418,12 +418,16 @@ class MixedLossFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------- evaluation metrics
-_eval_cache: dict = {"key": None, "stds": None, "out": None}
+_eval_cache: dict = {"refs": None, "meta": None, "stds": None, "out": None}
 
 
-def _eval_key(p, t, b, delta, lev):
-    return (p.data_ptr(), p._version, t.data_ptr(), t._version, b.data_ptr(), b._version, tuple(p.shape), float(delta),
-            int(lev), torch.cuda.current_stream().cuda_stream)
+def _eval_hit(p, t, b, meta) -> bool:
+    """the cached launch was made for exactly these three tensor OBJECTS (weak references: an address can be reused by
+    the allocator for the next batch, an object cannot), unmodified since (version counters), same parameters"""
+    refs = _eval_cache["refs"]
+    if refs is None or _eval_cache["meta"] != meta:
+        return False
+    return all(r() is x for r, x in zip(refs, (p, t, b)))
 
 
 def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequence[Optional[float]],
@@ -435,13 +439,15 @@ def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequen
     of the last launch is kept: the reference calls its ten metric modules one after the other on the same
     (prediction, target, mask), and every call after the first is a cache hit as long as the scales it needs agree
     with the ones the launch used (``optim_helper.evaluate`` makes the first call with the union of all scales)."""
+    import weakref
+    p0, t0, b0 = p, t, b
     p, t, b = p.detach().contiguous(), t.detach().contiguous(), b.detach().contiguous()
     B, c, Z, Y, X = p.shape
     if c != 4 or t.shape != p.shape or tuple(b.shape) != (B, 1, Z, Y, X):
         raise ValueError("eval_metrics expects p, t: (B,4,Z,Y,X) and masks: (B,1,Z,Y,X)")
-    key = _eval_key(p, t, b, delta, lev)
+    meta = (p0._version, t0._version, b0._version, float(delta), int(lev), torch.cuda.current_stream().cuda_stream)
     want = [None if v is None else float(v) for v in stds]
-    if _eval_cache["key"] == key and all(w is None or w == h for w, h in zip(want, _eval_cache["stds"])):
+    if _eval_hit(p0, t0, b0, meta) and all(w is None or w == h for w, h in zip(want, _eval_cache["stds"])):
         return _eval_cache["out"]
     used = [1.0 if w is None else w for w in want]
     ws = torch.empty(L.lib.sr3d_eval_metrics_workspace_bytes(B, Z, Y, X) // 4, dtype=torch.float32, device=p.device)
@@ -450,7 +456,8 @@ def eval_metrics(p: torch.Tensor, t: torch.Tensor, b: torch.Tensor, stds: Sequen
     L.check(L.lib.sr3d_eval_metrics(L.dev_ptr(p), L.dev_ptr(t), L.dev_ptr(b), B, Z, Y, X, sc, float(delta), int(lev),
                                     L.dev_ptr(out), L.dev_ptr(ws), L.stream_ptr()), "sr3d_eval_metrics")
     # entries a caller left open are NOT remembered as 1.0: a later caller that needs them must relaunch
-    _eval_cache.update(key=key, stds=[w if w is not None else float("nan") for w in want], out=out)
+    _eval_cache.update(refs=tuple(weakref.ref(x) for x in (p0, t0, b0)), meta=meta,
+                       stds=[w if w is not None else float("nan") for w in want], out=out)
     return out
 
 

@@ -177,3 +177,31 @@ def test_ssim3d_vs_reference(eng):
         got = float(eng.src.loss_maker.Ssim3dLoss()(p2.to(DEV), y2.to(DEV), b2.to(DEV)))
     ref = float(R.ssim3d(p2, y2, torch.broadcast_to(b2, p2.shape).contiguous(), eps=1e-3))
     assert abs(got - ref) < TOL
+
+
+def test_metric_cache_never_serves_another_batch(eng):
+    """the fused pass is cached per (prediction, target, mask) OBJECT: the next batch's tensors usually land at the same
+    addresses (caching allocator), and must still get their own launch"""
+    lm = eng.src.loss_maker
+    fn_a, fn_b = lm.MaskedL1Loss(), lm.AbsDiffTemperature(STDS[0])
+    vals = []
+    for seed in (1, 2, 3):
+        _, b, y = synthetic_inputs(1, (8, 16, 24), 4, seed, "iid")
+        p = y + 0.1 * seed * torch.rand(y.shape, generator=torch.Generator().manual_seed(seed))
+        pd, yd, bd = p.to(DEV), y.to(DEV), b.to(DEV)
+        with torch.no_grad():
+            got = (float(fn_a(pd, yd, bd)), float(fn_b(pd, yd, bd)))
+        ref = R.eval_metrics(p, y, b, STDS)
+        assert abs(got[0] - float(ref["MaskedL1"])) <= TOL * float(ref["MaskedL1"]), seed
+        assert abs(got[1] - float(ref["AbsDiffTemperature"])) <= TOL * float(ref["AbsDiffTemperature"]), seed
+        vals.append(got)
+        del pd, yd, bd            # freed: the next iteration's tensors reuse these addresses
+    assert len(set(vals)) == 3
+    # an in-place change of the prediction invalidates the entry too
+    _, b, y = synthetic_inputs(1, (8, 16, 24), 4, 9, "iid")
+    pd, yd, bd = (y + 0.1).to(DEV), y.to(DEV), b.to(DEV)
+    with torch.no_grad():
+        v1 = float(fn_a(pd, yd, bd))
+        pd.add_(0.05)
+        v2 = float(fn_a(pd, yd, bd))
+    assert abs(v2 - v1 - 0.05) < 1e-5

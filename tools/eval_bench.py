@@ -43,10 +43,10 @@ def main():
                 t_inf = timed(lambda: model(x, b), args.iters)
                 print(f"inference  B={B} HR {hr}: {t_inf:8.2f} ms  = {vox / t_inf / 1e3:.1f} M voxels/s")
             p = torch.rand_like(y)
-            sr3d_amd.ops._eval_cache["key"] = None
+            sr3d_amd.ops._eval_cache["refs"] = None
 
             def metrics():
-                sr3d_amd.ops._eval_cache["key"] = None     # defeat the per-batch cache: time the kernel
+                sr3d_amd.ops._eval_cache["refs"] = None    # defeat the per-batch cache: time the kernel
                 return sr3d_amd.ops.eval_metrics(p, y, b, stds)
             t_m = timed(metrics, args.iters)
             print(f"metrics    B={B} HR {hr}: {t_m:8.3f} ms  = {36.0 * vox / (t_m * 1e-3) / 1e9:.0f} GB/s of 36 B/voxel "
