@@ -3,8 +3,6 @@
 kernel (``ops.ssim3d``): the reference's w x w x w window is the triple outer product of its 1-D taps, so filtering
 along x, y and z with those taps gives the same sums with 33 instead of 1331 taps per voxel.  Forward only."""
 from logging import getLogger
-from math import exp
-
 import torch
 
 from .. import ops
@@ -13,13 +11,14 @@ logger = getLogger()
 
 
 def gaussian(window_size: int, sigma: float) -> torch.Tensor:
-    g = torch.Tensor([exp(-((x - window_size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(window_size)])
-    return g / g.sum()
+    """normalised 1-D Gaussian taps centred on window_size // 2 (fp32, as the reference's window)"""
+    offs = torch.arange(window_size, dtype=torch.float64) - (window_size // 2)
+    taps = torch.exp(-offs.square() / (2.0 * float(sigma) ** 2)).to(torch.float32)
+    return taps / taps.sum()
 
 
 def uniform(window_size: int) -> torch.Tensor:
-    u = torch.ones(window_size)
-    return u / u.sum()
+    return torch.ones(window_size) / window_size
 
 
 def create_window_3D(window_size: int, channel: int, sigma: float, use_gaussian: bool = True) -> torch.Tensor:
