@@ -1,8 +1,12 @@
-"""Train / validation loops with the reference's signatures
-(pytorch/src/optim_helper.py:22-225).  The step body is unchanged; ``optimizer``
-is any object with ``zero_grad()/step()`` (``FlatAdam`` or a torch optimizer) and,
-for the DDP variants, gradient averaging is the engine's ``GradAllReducer``
-(``reducer`` argument) instead of a ``DistributedDataParallel`` wrapper."""
+"""Train / validation / evaluation loops behind the reference's signatures (pytorch/src/optim_helper.py:22-225:
+``train``, ``test``, ``evaluate``, ``train_ddp``, ``test_ddp``).
+
+All five are thin drivers over three pieces: ``_device_batches`` (the sample tuple of the DataLoader -> device tensors,
+mask with its channel dimension), ``_train_step`` (forward, loss or GradNorm terms, backward, optional gradient
+all-reduce, optimizer) and ``_eval_loss``.  ``optimizer`` is any object with ``zero_grad()`` / ``step()`` (``FlatAdam``,
+a torch optimizer, or the pair train_model.py builds for GradNorm); in the DDP variants gradient averaging is the engine's
+``GradAllReducer`` (``reducer``) instead of a ``DistributedDataParallel`` wrapper, and the epoch loss stays on the device
+until the one all-reduce at the end."""
 import typing
 from logging import getLogger
 
@@ -14,35 +18,45 @@ logger = getLogger()
 
 
 class AverageMeter:
-    """running average (pytorch/src/utils.py:52-67)"""
+    """weighted running mean with the attributes the reference's meter exposes (pytorch/src/utils.py:52-67)"""
 
     def __init__(self):
         self.reset()
 
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
+    def reset(self) -> None:
+        self.val, self.sum, self.count = 0, 0, 0
 
-    def update(self, val, n=1):
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
+
+    def update(self, val, n: int = 1) -> None:
         self.val = val
         self.sum += val * n
         self.count += n
-        self.avg = self.sum / self.count
+
+
+def _device_batches(dataloader, device, num_loops: int = 1):
+    """(Xs, bs[with channel dim], ys) on `device`, `num_loops` passes over the loader"""
+    for _ in range(num_loops):
+        for Xs, bs, ys in dataloader:
+            yield Xs.to(device), bs.unsqueeze(1).to(device), ys.to(device)
 
 
 def _last_params(model):
     return (model.module if hasattr(model, "module") else model).get_last_params()
 
 
-def _step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer=None):
+def _train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm=None, reducer=None):
     preds = model(Xs, bs)
     if grad_norm is None:
         loss = loss_fn(preds, ys, bs)
         optimizer.zero_grad()
         loss.backward()
-    else:
-        losses = loss_fn.calc_loss_terms(predicts=preds, targets=ys, masks=bs)
+    else:   # GradNorm differentiates the individual terms (optim_helper.py:44-60, 167-178)
+        terms = loss_fn.calc_loss_terms(predicts=preds, targets=ys, masks=bs)
         optimizer.zero_grad()
-        loss = grad_norm.backward(loss_list=list(losses), last_shared_params=_last_params(model))
+        loss = grad_norm.backward(loss_list=list(terms), last_shared_params=_last_params(model))
     if reducer is not None:
         optimizer.grad_scale = reducer.finish()
     optimizer.step()
@@ -51,100 +65,89 @@ def _step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer=None):
     return loss
 
 
+_step = _train_step     # name used by tests / earlier rounds
+
+
+def _eval_loss(model, loss_fn, Xs, bs, ys, grad_norm=None):
+    preds = model(Xs, bs)
+    if grad_norm is None:
+        return loss_fn(preds, ys, bs)
+    terms = loss_fn.calc_loss_terms(predicts=preds, targets=ys, masks=bs)
+    return grad_norm.calc_total_weighted_loss_for_test(list(terms))
+
+
 def train(dataloader, model: nn.Module, loss_fn, optimizer, device: str, num_loops: int = 1,
           hide_progress_bar: bool = True, grad_norm=None) -> float:
     """optim_helper.py:22-66"""
-    train_loss = AverageMeter()
+    meter = AverageMeter()
     model.train()
-    for _ in range(num_loops):
-        for Xs, bs, ys in dataloader:
-            bs = bs.unsqueeze(1)  # add channel dim
-            Xs, bs, ys = Xs.to(device), bs.to(device), ys.to(device)
-            loss = _step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm)
-            train_loss.update(loss.item(), n=len(Xs))
-    logger.info(f"Train error: avg loss = {train_loss.avg:.8f}")
-    return train_loss.avg
+    for Xs, bs, ys in _device_batches(dataloader, device, num_loops):
+        meter.update(_train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm).item(), n=len(Xs))
+    logger.info(f"Train error: avg loss = {meter.avg:.8f}")
+    return meter.avg
 
 
 def test(dataloader, model: nn.Module, loss_fn, device: str, num_loops: int = 1, hide_progress_bar: bool = True,
          grad_norm=None) -> float:
     """optim_helper.py:69-108"""
-    val_loss = AverageMeter()
+    meter = AverageMeter()
     model.eval()
     with torch.no_grad():
-        for _ in range(num_loops):
-            for Xs, bs, ys in dataloader:
-                bs = bs.unsqueeze(1)
-                Xs, bs, ys = Xs.to(device), bs.to(device), ys.to(device)
-                preds = model(Xs, bs)
-                if grad_norm is None:
-                    loss = loss_fn(preds, ys, bs)
-                else:
-                    losses = loss_fn.calc_loss_terms(predicts=preds, targets=ys, masks=bs)
-                    loss = grad_norm.calc_total_weighted_loss_for_test(list(losses))
-                val_loss.update(loss.item(), n=len(Xs))
-    logger.info(f"Valid error: avg loss = {val_loss.avg:.8f}")
-    return val_loss.avg
+        for Xs, bs, ys in _device_batches(dataloader, device, num_loops):
+            meter.update(_eval_loss(model, loss_fn, Xs, bs, ys, grad_norm).item(), n=len(Xs))
+    logger.info(f"Valid error: avg loss = {meter.avg:.8f}")
+    return meter.avg
 
 
 def evaluate(*, dataloader, model: nn.Module, loss_fns: typing.Dict[str, typing.Callable], device: str,
              hide_progress_bar: bool = True) -> dict:
-    """optim_helper.py:111-134"""
+    """optim_helper.py:111-134: {name: AverageMeter} of every metric over the loader.  The engine's fused metrics all
+    come out of ONE pass per batch: it is launched here with the union of the scales the metrics depend on, and each
+    module then reads its entry."""
     from .. import ops
     from .loss_maker import _FusedMetric, merged_metric_scales
-    dict_loss = {k: AverageMeter() for k in loss_fns.keys()}
+    meters = {name: AverageMeter() for name in loss_fns}
     fused = [fn for fn in loss_fns.values() if isinstance(fn, _FusedMetric)]
     scales = merged_metric_scales(fused)
     with torch.no_grad():
-        for Xs, bs, ys in dataloader:
-            bs = bs.unsqueeze(1)
-            Xs, bs, ys = Xs.to(device), bs.to(device), ys.to(device)
+        for Xs, bs, ys in _device_batches(dataloader, device):
             preds = model(Xs, bs)
-            if fused:   # ONE pass over (preds, ys, bs) with the union of the scales: every fused metric below hits it
+            if fused:
                 ops.eval_metrics(preds, ys, bs, scales, fused[0].delta_meter, 0)
-            vals = {name: fn(preds, ys, bs) for name, fn in loss_fns.items()}
-            for name, v in vals.items():     # one host sync per metric only after everything is enqueued
-                dict_loss[name].update(v.item(), n=len(Xs))
-    return dict_loss
+            values = {name: fn(preds, ys, bs) for name, fn in loss_fns.items()}
+            for name, v in values.items():     # host syncs only after everything is enqueued
+                meters[name].update(v.item(), n=len(Xs))
+    return meters
+
+
+def _epoch_mean_over_ranks(total: torch.Tensor, count: int, world_size: int) -> float:
+    """sample-weighted mean of this rank, then the mean over ranks (one all-reduce per epoch)"""
+    mean = total / count
+    dist.all_reduce(mean, op=dist.ReduceOp.SUM)
+    return mean.item() / world_size
 
 
 def train_ddp(dataloader, sampler, model: nn.Module, loss_fn, optimizer, epoch: int, rank: int, world_size: int,
               num_loops: int, grad_norm=None, reducer=None) -> float:
-    """optim_helper.py:137-183; the loss stays on the device until the epoch-end all-reduce"""
-    mean_loss, cnt = 0.0, 0
+    """optim_helper.py:137-183"""
     sampler.set_epoch(epoch)
     model.train()
-    for _ in range(num_loops):
-        for Xs, bs, ys in dataloader:
-            bs = bs.unsqueeze(1)
-            Xs, bs, ys = Xs.to(rank), bs.to(rank), ys.to(rank)
-            loss = _step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer)
-            mean_loss += loss.detach() * Xs.shape[0]
-            cnt += Xs.shape[0]
-    mean_loss /= cnt
-    dist.all_reduce(mean_loss, op=dist.ReduceOp.SUM)
-    return mean_loss.item() / world_size
+    total, count = 0.0, 0
+    for Xs, bs, ys in _device_batches(dataloader, rank, num_loops):
+        loss = _train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer)
+        total = total + loss.detach() * len(Xs)
+        count += len(Xs)
+    return _epoch_mean_over_ranks(total, count, world_size)
 
 
 def test_ddp(dataloader, sampler, model: nn.Module, loss_fn, epoch: int, rank: int, world_size: int, num_loops: int,
              grad_norm=None) -> float:
     """optim_helper.py:186-225"""
-    mean_loss, cnt = 0.0, 0
     sampler.set_epoch(epoch)
     model.eval()
+    total, count = 0.0, 0
     with torch.no_grad():
-        for _ in range(num_loops):
-            for Xs, bs, ys in dataloader:
-                bs = bs.unsqueeze(1)
-                Xs, bs, ys = Xs.to(rank), bs.to(rank), ys.to(rank)
-                preds = model(Xs, bs)
-                if grad_norm is None:
-                    loss = loss_fn(preds, ys, bs)
-                else:
-                    losses = loss_fn.calc_loss_terms(predicts=preds, targets=ys, masks=bs)
-                    loss = grad_norm.calc_total_weighted_loss_for_test(list(losses))
-                mean_loss += loss * Xs.shape[0]
-                cnt += Xs.shape[0]
-    mean_loss /= cnt
-    dist.all_reduce(mean_loss, op=dist.ReduceOp.SUM)
-    return mean_loss.item() / world_size
+        for Xs, bs, ys in _device_batches(dataloader, rank, num_loops):
+            total = total + _eval_loss(model, loss_fn, Xs, bs, ys, grad_norm) * len(Xs)
+            count += len(Xs)
+    return _epoch_mean_over_ranks(total, count, world_size)

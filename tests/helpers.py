@@ -69,3 +69,16 @@ def sampled(t, n_full=20000, n_samp=4096):
     while any(n % q == 0 for q in range(2, int(n ** 0.5) + 1)):      # smallest prime >= n, as in make_golden.py
         n += 1
     return flat[::n]
+
+
+def trimmed_relerr(a, b, frac=0.0025):
+    """normwise error after discarding the `frac` of elements with the largest error (at least one): for quantities
+    in which a handful of elements are legitimately ill-conditioned (a flipped activation decision; an Adam update of
+    a gradient element within eps of zero) while a wrong tile or tap would touch far more than that"""
+    a = torch.as_tensor(a).detach().double().cpu().flatten()
+    b = torch.as_tensor(b).detach().double().cpu().flatten()
+    e2 = (a - b) ** 2
+    drop = max(1, int(frac * e2.numel()))
+    kept = e2.sum() - torch.topk(e2, drop).values.sum()
+    den = float(b.norm())
+    return float(kept.clamp_min(0).sqrt()) / den if den > 0 else float(kept.clamp_min(0).sqrt())
