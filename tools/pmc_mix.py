@@ -10,8 +10,9 @@ import json
 import os
 import sys
 
-FAMILIES = {"wino_kernel": "wino_kernel", "wino_wgrad_kernel": "wino_wgrad_kernel", "igemm_s2_fwd": "igemm_kernelILi2",
-            "igemm_s2_bwd": "igemm_kernelILi1ELi0", "wgrad_direct": "12wgrad_kernel"}
+# substrings of the (demangled) kernel names in rocprofv3's counter CSV; first match wins
+FAMILIES = {"wino_wgrad_kernel": "wino_wgrad_kernel", "wino_kernel": "wino_kernel", "igemm_s2_fwd": "igemm_kernel<2,",
+            "igemm_s2_bwd": "igemm_kernel<1, 0,", "igemm_s1": "igemm_kernel<1, -1,", "wgrad_direct": "::wgrad_kernel<"}
 csv.field_size_limit(1 << 30)
 
 
@@ -23,7 +24,7 @@ def main():
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"]
                 for fam, pat in FAMILIES.items():
-                    if pat in name or pat.lstrip("0123456789") + "<" in name:
+                    if pat in name:
                         a = acc.setdefault(fam, {"_ids": {}})
                         a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                         a["_ids"].setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])

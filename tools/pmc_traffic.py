@@ -9,8 +9,8 @@ import json
 import os
 import sys
 
-KERNELS = {"igemm_s1": "wino_kernel", "wgrad": "wino_wgrad_kernel", "igemm_s2": "igemm_kernelILi2",
-           "wgrad_direct": "wgrad_kernel"}
+KERNELS = {"igemm_s1": "wino_kernel", "wgrad": "wino_wgrad_kernel", "igemm_s2": "igemm_kernel<2,",
+           "igemm_bwd_s2": "igemm_kernel<1, 0,", "wgrad_direct": "::wgrad_kernel<"}
 
 
 def collect(d, counter):
@@ -21,7 +21,7 @@ def collect(d, counter):
                 continue
             name = row["Kernel_Name"]
             for key, pat in KERNELS.items():
-                if pat in name and not (key == "wgrad_direct" and "wino" in name):
+                if pat in name:
                     s = out.setdefault(key, {"sum": 0.0, "ids": set()})
                     s["sum"] += float(row["Counter_Value"])
                     s["ids"].add(row.get("Dispatch_Id"))
