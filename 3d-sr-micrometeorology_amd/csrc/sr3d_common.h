@@ -77,6 +77,33 @@ size_t sr3d_wino_image_floats(int rows, int K);
 int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                    const int* cbeg, float* image, hipStream_t st);
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st);
+// launch description of the split-f16 stride-1 conv (sr3d_hconv.hip, opt-in with SR3D_SPLIT_F16=1)
+struct SrHconvParams {
+  ChanCat in;          // K side (virtual concat)
+  int K;               // input channels
+  int Z, Y, X;
+  int ntz, nty, ntx, nblk, nchunks;   // set by sr3d_hconv_launch
+  int nb_off;          // first row block of this launch inside its image region
+  const void* wimg;    // split + packed weights (region base)
+  const float* absmax_x;   // device: max |x| over the K-side tensors of this call
+  const float* absmax_w;   // device: max |w| (header of the packed image)
+  int N;               // GEMM rows (gated: 64 per 32 channels)
+  int n_off;
+  int epi, act;
+  const float* bias;
+  const float* bias2;
+  ChanCat out;
+  float* y;
+  float* save_f;
+  float* save_s;
+  int TZ_, TY_, TX_;
+  int unsh_C, Cg;
+};
+bool sr3d_hconv_enabled();
+size_t sr3d_hconv_image_bytes(int rows, int K);
+int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
+                    const int* cbeg, void* image, hipStream_t st);
+int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st);
 // Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
 // (the first `c_used` input channels; dW rows keep their full length d->Cin * 27)
 size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);

@@ -1,0 +1,584 @@
+// Stride-1 3x3x3 convolution (forward and input gradient) with fp32 operands split into two fp16 halves, on
+// v_mfma_f32_32x32x16_f16 -- OPT-IN (SR3D_SPLIT_F16=1), the fp32 Winograd kernel stays the default.
+//
+// Why: gfx950's fp32 MFMA runs at 1/16 of the f16 rate.  An fp32 value scaled into [2^13, 2^14) splits EXACTLY into
+// hi = fp16(a) and lo = fp16(a - hi) with |a - hi - lo| <= 2^-22 |a|, and
+//        a * b  =  hi_a hi_b + hi_a lo_b + lo_a hi_b  (+ lo_a lo_b ~ 2^-22 |a b|, dropped)
+// accumulated in the MFMA's fp32 accumulator: three f16 MFMAs (K = 16 each, 32 cycles) replace eight fp32 MFMAs
+// (K = 2, 64 cycles), 5.3x less matrix-pipe time per product at a per-product error of ~2^-21, the size of fp32's own
+// rounding in a 27 K-term sum.  The Winograd form of this does not fit the CU (K = 16 channels of V for 5 planes x
+// 16 points x 32 tiles are 164 KB of LDS), so this is a DIRECT implicit GEMM: 81 f16 MFMAs per (32 rows x 32 voxels
+// x 16 channels) = 2592 cycles, against 6144 for fp32 Winograd.
+//
+// Scaling: per launch, in_mult = 2^sa and w_mult = 2^sw are exact powers of two taken from max|x| (one HBM pass,
+// absmax_kernel) and max|w| (at packing time) so that the largest element lands in [2^13, 2^14): no fp16 overflow for
+// any input, gradients of 1e-9 keep their 22 bits, elements 2^-14 below the maximum lose only what is below 2^-36 of
+// it.  The epilogue multiplies by 2^-(sa+sw).
+//
+// One 512-thread workgroup (alone on its CU): 64 (or 32) output rows x 4 x 4 x 32 voxels; wave w owns voxel rows
+// 2w, 2w+1 for all row tiles.  Chunk = 16 channels = K of one MFMA.
+//   halo      [part][channel half][voxel 6x6x34][8 ch] fp16 (80 KB): raw fp32 rows come in by buffer loads with
+//             hardware range checks one chunk ahead (registers), are scaled, split and written as 16-byte pieces;
+//             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
+//   weights   split + packed once per call: [row block][chunk][kz][ky,kx][part][row tile][64 lanes][8 ch]; one kz
+//             phase (36 KB) arrives by LDS-DMA while the previous one is multiplied (two buffers)
+#include "sr3d_common.h"
+
+#include <limits.h>
+#include <stdlib.h>
+
+#include <atomic>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int HKC = 16;                        // channels per chunk
+constexpr int HHZ = 6, HHY = 6, HHX = 34;      // halo of the 4 x 4 x 32 voxel tile
+constexpr int HVOX = HHZ * HHY * HHX;          // 1224
+constexpr int HVP = 1280;                      // voxels per plane, padded to 20 waves
+constexpr int HPLANE = HVP * 16;               // bytes of one (part, channel half) plane
+constexpr int HBYTES = 4 * HPLANE;             // 81920
+constexpr int HNT = 512;
+template <int RT>
+struct HGeo {
+  static constexpr int PIECES = 9 * 2 * RT;    // 1 KB fragments of one kz phase
+  static constexpr int WPHASE = PIECES * 1024;
+  static constexpr size_t LDS = HBYTES + 2 * (size_t)WPHASE;
+};
+static_assert(HGeo<2>::LDS <= 160 * 1024, "LDS budget");
+
+typedef __attribute__((address_space(3))) void* lds_p;
+
+__device__ __forceinline__ float hact(float v, int act) {
+  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+// exponent s with amax * 2^s in [2^13, 2^14) (0 for amax = 0 or not finite)
+__device__ __forceinline__ int scale_exp(float amax) {
+  if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+  int e;
+  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  return 14 - e;
+}
+
+// 16 bytes per lane, global -> LDS, buffer form.  (Device pass only: the host pass of hipcc rejects the 16-byte size
+// of this builtin -- it checks it against the host's feature set -- and then drops the kernel's stub without a message.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_p dst, int voffset) {
+#if __HIP_DEVICE_COMPILE__
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
+// keeps a wave-uniform value in a scalar register and opaque to the optimiser
+template <typename T>
+__device__ __forceinline__ void pin_scalar(T& x) {
+  asm volatile("" : "+s"(x));
+}
+
+template <int RT>
+__global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
+  using G = HGeo<RT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Hs = lds;
+  unsigned char* Ws = lds + HBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // workgroup -> (row block, voxel tile); the row blocks of one tile run next to each other on one XCD
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = v % p.nblk;
+  int blk = v / p.nblk;
+  const int tix = blk % p.ntx;
+  blk /= p.ntx;
+  const int tiy = blk % p.nty;
+  const int tiz = blk / p.nty;
+  const int b = blockIdx.y;
+  const int z0 = tiz * 4, y0 = tiy * 4, x0 = tix * 32;
+  const long long ZYX = (long long)p.Z * p.Y * p.X;
+  const int chan_bytes = (int)(ZYX * 4);
+
+  const int sa = scale_exp(*p.absmax_x), sw = scale_exp(*p.absmax_w);
+  const float in_mult = ldexpf(1.f, sa), out_mult = ldexpf(1.f, -(sa + sw));
+
+  // ---- staging geometry: this wave stages channel half `sh` of every chunk, voxel blocks r * 4 + (wave >> 1)
+  const int sh = wave & 1;
+  unsigned soff[5];   // byte offset inside a channel volume, 0xffffffff = zero padding
+  int swr[5];         // byte offset of the 16-byte piece inside a halo plane
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int e = (r * 4 + (wave >> 1)) * 64 + lane;
+    const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
+    const int hy = r2 / HHX, hx = r2 - hy * HHX;
+    const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool ok = e < HVOX && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
+    soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
+    swr[r] = e * 16;
+  }
+  // Per-slice base pointers of this sample, pinned in scalar registers: left to itself hipcc turns the slice selects into
+  // dependent kernel-argument loads (two or three ~200-cycle scalar-load round trips per channel, in every wave, at the
+  // start of every chunk).
+  // (separate variables, not arrays: an array would be indexed in scratch memory)
+#define SR3D_SLICE_BASE(i) reinterpret_cast<unsigned long long>(p.in.ptr[i] + (long long)b * p.in.bstride[i])
+  unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
+#undef SR3D_SLICE_BASE
+  int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
+  pin_scalar(sb0), pin_scalar(sb1), pin_scalar(sb2), pin_scalar(sb3);
+  pin_scalar(cb0), pin_scalar(cb1), pin_scalar(cb2), pin_scalar(cb3);
+  auto slice_of = [&](const int gc) { return (gc >= cb1) + (gc >= cb2) + (gc >= cb3); };
+  // (mask arithmetic instead of selects: hipcc turns a select chain over four values into a lookup table in scratch)
+  unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
+  int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
+  pin_scalar(dsb1), pin_scalar(dsb2), pin_scalar(dsb3), pin_scalar(dcb1), pin_scalar(dcb2), pin_scalar(dcb3);
+  auto chan_base = [&](const int gc) {   // gc is wave-uniform
+    const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
+    const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
+    const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
+    return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
+  };
+  float raw[5][8];
+  auto load_raw = [&](const int chunk) {
+    const int gc0 = chunk * HKC + sh * 8;      // wave-uniform
+    const int first = gc0 < p.K ? gc0 : p.K - 1, last = gc0 + 7 < p.K ? gc0 + 7 : p.K - 1;
+    unsigned long long cbase[8];
+    if (slice_of(first) == slice_of(last)) {   // the usual case: 8 consecutive channels of one tensor
+      const unsigned long long b0 = chan_base(first);
+#pragma unroll
+      for (int c = 0; c < 8; c++) cbase[c] = b0 + (unsigned long long)c * (unsigned)chan_bytes;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; c++) cbase[c] = chan_base(gc0 + c < p.K ? gc0 + c : p.K - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase[c], 0, gc0 + c < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 5; r++) raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
+    }
+  };
+  auto write_halo = [&]() {
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      h8 hi, lo;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float s = raw[r][c] * in_mult;
+        const _Float16 a = (_Float16)s;
+        hi[c] = a;
+        lo[c] = (_Float16)(s - (float)a);
+      }
+      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;
+      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
+    }
+  };
+  // one kz phase of the packed weights: PIECES contiguous 1 KB fragments, LDS-DMA.  (The buffer form on purpose: the
+  // global_load_lds form is a FLAT instruction that touches two address spaces, and while one is pending hipcc turns
+  // every LDS wait into lgkmcnt(0) -- the register double-buffering of the fragments below would wait for the reads
+  // it has just issued.)
+  const unsigned char* wblock = reinterpret_cast<const unsigned char*>(p.wimg) + (size_t)(p.nb_off + nblk) * p.nchunks * 3 * G::WPHASE;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wblock, 0, p.nchunks * 3 * G::WPHASE, 0x00020000);
+  auto dma_w = [&](const int phase, unsigned char* W) {   // phase = chunk * 3 + kz
+#pragma unroll
+    for (int ii = 0; ii < (G::PIECES + 7) / 8; ii++) {
+      const int i = wave + 8 * ii;
+      if (i < G::PIECES)
+        lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
+    }
+  };
+
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // B fragment bases: voxel row vt = 2 * wave + j -> (z, y) = (vt >> 2, vt & 3)
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int vt = 2 * wave + j;
+    bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
+  }
+  const int abase = lane * 16;
+
+  // ---- prologue
+  const int nphases = p.nchunks * 3;
+  dma_w(0, Ws);
+  load_raw(0);
+  write_halo();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // fragments are double-buffered in registers: the reads of tap t+1 are issued before the MFMAs of tap t
+  h8 fa[2][2][RT], fb[2][2][2];   // [set][part][row tile], [set][part][voxel row]
+  // (issued in two groups of 4: more than 15 LDS reads in flight overflow the lgkmcnt counter and the compiler then
+  // waits for all of them)
+  auto frags_a = [&](const int set, const unsigned char* W, const int t) {
+#pragma unroll
+    for (int part = 0; part < 2; part++)
+#pragma unroll
+      for (int i = 0; i < RT; i++) fa[set][part][i] = *reinterpret_cast<const h8*>(W + ((t * 2 + part) * RT + i) * 1024);
+  };
+  auto frags_b = [&](const int set, const unsigned char* Hk, const int t) {
+    const int toff = ((t / 3) * HHX + (t % 3)) * 16;
+#pragma unroll
+    for (int part = 0; part < 2; part++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[set][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + toff);
+  };
+  auto mfmas = [&](const int set, const int i) {   // row tile i
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][1][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][1][i], fb[set][0][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  h8 chi[5], clo[5];   // the next chunk's halo pieces, split during the last kz phase
+  auto convert = [&]() {
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float sc = raw[r][c] * in_mult;
+        const _Float16 a = (_Float16)sc;
+        chi[r][c] = a;
+        clo[r][c] = (_Float16)(sc - (float)a);
+      }
+  };
+
+  int phase = 0;
+  for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+    for (int kz = 0; kz < 3; kz++, phase++) {
+      const unsigned char* W = Ws + (phase & 1) * G::WPHASE + abase;
+      if (phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
+      const unsigned char* Hk = Hs + kz * (HHY * HHX * 16);
+      frags_a(0, W, 0);
+      frags_b(0, Hk, 0);
+      if (kz == 2) convert();   // (the raw rows landed before the barrier of phase 0)
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        if (t + 1 < 9) frags_a((t + 1) & 1, W, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(t & 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 9) frags_b((t + 1) & 1, Hk, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RT == 2) mfmas(t & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (chunk + 1 < p.nchunks) {
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
+        *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue (direct 32 x 32 layout)
+  const int ox = x0 + (lane & 31);
+  const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
+  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
+  if (ox >= p.X) return;
+  if (p.epi == SR3D_EPI_GATED) {
+    if constexpr (RT == 2) {
+      const int cbase = rblock / 2 + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int vt = 2 * wave + j;
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+        if (oz >= p.Z || oy >= p.Y) continue;
+        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2);
+          if (co < p.Cg) {
+            float f = acc[0][j][r] * out_mult;
+            if (p.bias) f += p.bias[co];
+            const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
+            const float s = 1.f / (1.f + expf(-g));
+            f = hact(f, p.act);
+            const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+            p.y[o] = s * f;
+            if (p.save_f) {
+              p.save_f[o] = f;
+              p.save_s[o] = s;
+            }
+          }
+        }
+      }
+    }
+  } else if (p.epi == SR3D_EPI_UNSHUFFLE) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int vt = 2 * wave + j;
+      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+      if (oz >= p.Z || oy >= p.Y) continue;
+#pragma unroll
+      for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+          if (n < p.N) {
+            const float val = hact(acc[i][j][r] * out_mult + p.bias[n], p.act);
+            const int f = n / p.unsh_C, c = n - f * p.unsh_C;
+            const long long o = ((long long)b * p.unsh_C + c) * TZYX +
+                                ((long long)(2 * oz + (f >> 2)) * p.TY_ + (2 * oy + ((f >> 1) & 1))) * p.TX_ + (2 * ox + (f & 1));
+            p.y[o] = val;
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        if (n >= p.N) continue;
+        const int si = cat_find(p.out, n);
+        float* base = cat_ptr(p.out, si);
+        if (base == nullptr) continue;
+        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int vt = 2 * wave + j;
+          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+          if (oz < p.Z && oy < p.Y) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = hact(acc[i][j][r] * out_mult + bv, p.act);
+        }
+      }
+  }
+}
+
+// ---- max |x| of a tensor into *slot (bits of a non-negative float order like unsigned integers)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* slot) {
+  float m = 0.f;
+  const long long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 q = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
+// ---- weight split + packing: image [row block][chunk][tap 27][part][row tile][channel half][32 rows][8 ch] fp16
+struct HPackParams {
+  const float* w1;
+  const float* w2;
+  const float* absmax_w;
+  _Float16* img;
+  int Cout, Cin, kind, K, N, nchunks, nblk, RT, n_off;
+  int rbeg[SR3D_MAX_SRC + 1];
+  int cbeg[SR3D_MAX_SRC];
+};
+
+__global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
+  const float w_mult = ldexpf(1.f, scale_exp(*p.absmax_w));
+  const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;   // items of 8 channels
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    long long r = e;
+    const int row = r % 32;
+    r /= 32;
+    const int h = r % 2;
+    r /= 2;
+    const int rt = r % p.RT;
+    r /= p.RT;
+    const int tap = r % 27;
+    r /= 27;
+    const int chunk = r % p.nchunks;
+    const int nb = r / p.nchunks;
+    const int n = p.n_off + nb * (32 * p.RT) + rt * 32 + row;
+    const float* w = nullptr;   // -> w[.][k = 0][tap 0]; element (k, tap) at w[k * kstride + tapidx]
+    long long kstride = 27;
+    int tapidx = tap;
+    if (p.kind == SR3D_PACK_FWD) {
+      if (n < p.N) w = p.w1 + (long long)n * p.Cin * 27;
+    } else if (p.kind == SR3D_PACK_FWD_GATED) {
+      const int co = (n >> 6) * 32 + (n & 31);   // 64-row block = 32 feature rows, then the 32 gate rows
+      if (co < p.Cout) w = ((n & 32) ? p.w2 : p.w1) + (long long)co * p.Cin * 27;
+    } else if (n < p.N) {   // input gradient: rows = input channels that need a gradient, K = output channels, taps mirrored
+      const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
+      const int ci = p.cbeg[si] + (n - p.rbeg[si]);
+      w = p.w1 + (long long)ci * 27;
+      kstride = (long long)p.Cin * 27;
+      tapidx = 26 - tap;
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = chunk * HKC + h * 8 + j;
+      float val = 0.f;
+      if (w != nullptr && k < p.K) {
+        if (p.kind == SR3D_PACK_BWD || p.kind == SR3D_PACK_BWD_GATED) {
+          const float* src = k < p.Cout ? w + (long long)k * kstride : (p.w2 + (w - p.w1)) + (long long)(k - p.Cout) * kstride;
+          val = src[tapidx];
+        } else {
+          val = w[(long long)k * kstride + tapidx];
+        }
+      }
+      const float s = val * w_mult;
+      const _Float16 a = (_Float16)s;
+      hi[j] = a;
+      lo[j] = (_Float16)(s - (float)a);
+    }
+    const long long piece0 = ((((long long)nb * p.nchunks + chunk) * 27 + tap) * 2 + 0) * p.RT + rt;
+    const long long piece1 = piece0 + p.RT;
+    *reinterpret_cast<h8*>(p.img + piece0 * 512 + (h * 32 + row) * 8) = hi;
+    *reinterpret_cast<h8*>(p.img + piece1 * 512 + (h * 32 + row) * 8) = lo;
+  }
+}
+
+constexpr int kSlots = 256;
+unsigned* absmax_slots() {   // device scratch, one slot per call (calls on a stream are ordered anyway)
+  static unsigned* slots = nullptr;
+  static std::atomic<int> ready{0};
+  static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+  if (!ready.load(std::memory_order_acquire)) {
+    while (busy.test_and_set(std::memory_order_acquire)) {
+    }
+    if (!ready.load(std::memory_order_relaxed)) {
+      void* ptr = nullptr;
+      if (hipMalloc(&ptr, kSlots * sizeof(unsigned)) == hipSuccess) slots = (unsigned*)ptr;
+      ready.store(1, std::memory_order_release);
+    }
+    busy.clear(std::memory_order_release);
+  }
+  return slots;
+}
+std::atomic<unsigned> g_slot_counter{0};
+
+int absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st) {
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, slot);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+inline void row_split(int rows, int* n2, int* n1) {   // 64-row blocks, and one last block of <= 32 rows
+  const int nfull = rows / 64, rem = rows - nfull * 64;
+  *n2 = nfull + (rem > 32 ? 1 : 0);
+  *n1 = (rem > 0 && rem <= 32) ? 1 : 0;
+}
+
+}  // namespace
+
+bool sr3d_hconv_enabled() {
+  const char* e = getenv("SR3D_SPLIT_F16");   // read per call: tests and tools switch it at run time
+  return e != nullptr && atoi(e) != 0;
+}
+
+// header (64 bytes: max |w|) + region A (64-row blocks) + region B (one 32-row block)
+size_t sr3d_hconv_image_bytes(int rows, int K) {
+  int n2, n1;
+  row_split(rows, &n2, &n1);
+  return 64 + (size_t)ceil_div(K, HKC) * 3 * ((size_t)n2 * HGeo<2>::WPHASE + (size_t)n1 * HGeo<1>::WPHASE);
+}
+
+int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
+                    const int* cbeg, void* image, hipStream_t st) {
+  unsigned* hdr = (unsigned*)image;
+  SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
+  const long long nw = (long long)Cout * Cin * 27;
+  if (int rc = absmax_launch(w1, nw, hdr, st)) return rc;
+  if (w2 != nullptr)
+    if (int rc = absmax_launch(w2, nw, hdr, st)) return rc;
+  HPackParams p{};
+  p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
+  p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.nchunks = ceil_div(K, HKC);
+  for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
+  for (int i = 0; i < SR3D_MAX_SRC; i++) p.cbeg[i] = cbeg ? cbeg[i] : 0;
+  int n2, n1;
+  row_split(rows, &n2, &n1);
+  _Float16* body = (_Float16*)((unsigned char*)image + 64);
+  for (int region = 0; region < 2; region++) {
+    p.nblk = region == 0 ? n2 : n1;
+    if (p.nblk == 0) continue;
+    p.RT = region == 0 ? 2 : 1;
+    p.n_off = region == 0 ? 0 : n2 * 64;
+    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * 3 * (HGeo<2>::WPHASE / 2));
+    const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(hconv_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
+    SR3D_HIP(hipGetLastError());
+  }
+  return SR3D_OK;
+}
+
+int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st) {
+  SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "split-f16 conv: more than 2^29 voxels per channel");
+  SR3D_CHECK(B <= 65535, SR3D_E_ARG, "split-f16 conv: batch too large");
+  unsigned* slots = absmax_slots();
+  SR3D_CHECK(slots != nullptr, SR3D_E_HIP, "split-f16 conv: no device scratch");
+  unsigned* slot = slots + (g_slot_counter.fetch_add(1) % kSlots);
+  {
+    SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
+    SR3D_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
+    double bytes = 0;
+    for (int i = 0; i < p.in.n; i++) {
+      const long long n = (long long)B * p.in.bstride[i];
+      if (int rc = absmax_launch(p.in.ptr[i], n, slot, st)) return rc;
+      bytes += 4.0 * n;
+    }
+    (void)bytes;
+  }
+  p.absmax_x = (const float*)slot;
+  p.absmax_w = (const float*)image;
+  p.wimg = (const unsigned char*)image + 64;
+  p.ntz = ceil_div(p.Z, 4), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
+  p.nchunks = ceil_div(p.K, HKC);
+  int n2, n1;
+  row_split(p.N, &n2, &n1);
+  const long long nsp = (long long)p.ntz * p.nty * p.ntx;
+  SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
+  static thread_local bool configured = false;
+  if (!configured) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2>::LDS));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1>::LDS));
+    configured = true;
+  }
+  void* tok = nullptr;
+  if (sr3d_prof_active()) {
+    const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
+    sr3d_prof_begin(SR3D_PROF_HCONV, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
+  }
+  if (n2 > 0) {
+    p.nblk = n2, p.nb_off = 0;
+    hipLaunchKernelGGL(hconv_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(HNT), HGeo<2>::LDS, st, p);
+  }
+  if (n1 > 0) {
+    // region B: its blocks are 32 rows; express the offsets in the kernel's own units
+    SrHconvParams q = p;
+    q.nblk = 1, q.nb_off = 0;
+    q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * 3 * HGeo<2>::WPHASE;
+    q.n_off = p.n_off + n2 * 64;
+    hipLaunchKernelGGL(hconv_kernel<1>, dim3((unsigned)nsp, B), dim3(HNT), HGeo<1>::LDS, st, q);
+  }
+  sr3d_prof_end(tok, st);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}

@@ -442,6 +442,13 @@ inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
 inline bool use_wino(const sr3d_conv_desc_t* d) {
   return d->stride == 1 && sr3d_wino_enabled() && d->Cin <= SR3D_WINO_MAX_K && d->Cout <= SR3D_WINO_MAX_K;
 }
+// opt-in: stride-1 convolutions with >= 32 GEMM-K channels on the split-f16 kernel (sr3d_hconv.hip)
+inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
+  return d->stride == 1 && sr3d_hconv_enabled() && K >= 32 && rows >= 16;
+}
+inline int hconv_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
+  return kind == SR3D_PACK_FWD_GATED ? 64 * ((d->Cout + 31) / 32) : d->Cout;
+}
 inline int wino_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 32 * ((d->Cout + 15) / 16) : d->Cout;
 }
@@ -696,6 +703,7 @@ extern "C" {
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
+  if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_image_bytes(hconv_fwd_rows(d, kind), d->Cin);
   if (use_wino(d)) return sr3d_wino_image_floats(wino_fwd_rows(d, kind), d->Cin) * 4;
   return image_floats(ceil_div(fwd_rows(d, kind), 32), ceil_div(d->Cin, kKC), 27) * 4;
 }
@@ -712,6 +720,9 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
   }
+  if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)))
+    return sr3d_hconv_pack(kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
+                           (const float*)w_gate, nullptr, nullptr, w_packed, (hipStream_t)stream);
   if (use_wino(d))
     return sr3d_wino_pack(kind, d->Cout, d->Cin, wino_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                           (const float*)w_gate, nullptr, nullptr, (float*)w_packed, (hipStream_t)stream);
@@ -741,6 +752,25 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3(q.ntz * q.nty * q.ntx, d->B), dim3(256), 0, (hipStream_t)stream, q);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
+  }
+  if (use_hconv(d, d->Cin, d->Cout)) {
+    SrHconvParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
+    for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X, q.N = d->Cout;
+    q.act = act, q.bias = (const float*)bias;
+    if (unshuffle) {
+      SR3D_CHECK(d->Cout % 8 == 0 && bias != nullptr, SR3D_E_ARG,
+                 "conv3d_fwd: unshuffle needs Cout %% 8 == 0 and a bias (Cout = %d)", d->Cout);
+      q.epi = SR3D_EPI_UNSHUFFLE, q.y = (float*)y, q.unsh_C = d->Cout / 8;
+      q.TZ_ = 2 * d->Z, q.TY_ = 2 * d->Y, q.TX_ = 2 * d->X;
+    } else {
+      q.epi = SR3D_EPI_PLAIN;
+      sr3d_slice_t ys{y, d->Cout};
+      if (int rc = sr3d_make_cat(&ys, 1, (long long)d->Z * d->Y * d->X, d->Cout, &q.out, "y")) return rc;
+      q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    }
+    return sr3d_hconv_launch(q, w_packed, d->B, (hipStream_t)stream);
   }
   if (use_wino(d)) {
     SrWinoParams q{};
@@ -788,6 +818,18 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "gated_conv3d_fwd: null pointer");
   SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_conv3d_fwd: unknown activation %d", act);
+  if (use_hconv(d, d->Cin, hconv_fwd_rows(d, SR3D_PACK_FWD_GATED))) {
+    SrHconvParams q{};
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
+    for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.N = hconv_fwd_rows(d, SR3D_PACK_FWD_GATED), q.Cg = d->Cout;
+    q.act = act, q.epi = SR3D_EPI_GATED;
+    q.bias = (const float*)bias_f, q.bias2 = (const float*)bias_g;
+    q.y = (float*)y, q.save_f = (float*)save_f, q.save_s = (float*)save_s;
+    q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    return sr3d_hconv_launch(q, w_packed, d->B, (hipStream_t)stream);
+  }
   if (use_wino(d)) {
     SrWinoParams q{};
     if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
@@ -824,7 +866,11 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   const size_t direct = image_floats(ceil_div(d->Cin, 32), ceil_div(n_dy * d->Cout, kKC), 27) * 4;
   // (+ the [K][27][4] image of up to 4 remainder rows that take the VALU kernel)
   const size_t wino = use_wino(d) ? sr3d_wino_image_floats(d->Cin, n_dy * d->Cout) * 4 + (size_t)n_dy * d->Cout * 108 * 4 : 0;
-  return direct > wino ? direct : wino;
+  const size_t hc = use_hconv(d, n_dy * d->Cout, d->Cin)
+                        ? ((sr3d_hconv_image_bytes(d->Cin, n_dy * d->Cout) + 255) & ~(size_t)255) + (size_t)n_dy * d->Cout * 108 * 4
+                        : 0;
+  const size_t m = direct > wino ? direct : wino;
+  return m > hc ? m : hc;
 }
 
 int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
@@ -875,7 +921,8 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   pk.K = K, pk.N = rows, pk.nchunks = p.nchunks;
   float* image = (float*)workspace;
 
-  if (use_wino(d) && K <= SR3D_WINO_MAX_K) {
+  const bool hconv = use_hconv(d, K, rows);
+  if (hconv || (use_wino(d) && K <= SR3D_WINO_MAX_K)) {
     // 1..4 gradient rows beyond a multiple of 64 (e.g. 193 = 3 * 64 + 1) would cost a whole 32-row Winograd tile per
     // voxel block: when they are the last channels of the last destination slice they take the small-N VALU kernel
     int rem = rows % 64;
@@ -883,15 +930,27 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     // (on the small grids of the deep levels the extra launches cost more than the padded tile)
     if (!(rows > 64 && rem >= 1 && rem <= 4 && last.channels >= rem && (long long)d->Z * d->Y * d->X >= 500000)) rem = 0;
     const int main_rows = rows - rem;
-    SrWinoParams q{};
-    q.in = p.in, q.out = p.out;
-    q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
-    q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
-    q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE, q.up = image;
-    if (int rc = sr3d_wino_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
-    if (int rc = sr3d_wino_launch(q, d->B, st)) return rc;
+    float* wsm = nullptr;   // image of the remainder rows
+    if (hconv) {
+      SrHconvParams q{};
+      q.in = p.in, q.out = p.out;
+      q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+      q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+      q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
+      if (int rc = sr3d_hconv_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
+      if (int rc = sr3d_hconv_launch(q, image, d->B, st)) return rc;
+      wsm = (float*)((unsigned char*)image + ((sr3d_hconv_image_bytes(main_rows, K) + 255) & ~(size_t)255));
+    } else {
+      SrWinoParams q{};
+      q.in = p.in, q.out = p.out;
+      q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+      q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+      q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE, q.up = image;
+      if (int rc = sr3d_wino_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
+      if (int rc = sr3d_wino_launch(q, d->B, st)) return rc;
+      wsm = image + sr3d_wino_image_floats(main_rows, K);
+    }
     if (rem > 0) {
-      float* wsm = image + sr3d_wino_image_floats(main_rows, K);
       const int ci0 = pk.cbeg[nn - 1] + last.channels - rem;   // input channel of the first remainder row
       hipLaunchKernelGGL(pack_smalln_bwd_kernel, dim3(ceil_div(K * 108, 256)), dim3(256), 0, st, pk.w1, pk.w2, wsm, d->Cout,
                          d->Cin, K, ci0, rem);

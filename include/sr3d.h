@@ -247,7 +247,8 @@ enum {
   SR3D_PROF_DATA = 8,         /* upsample+concat, mask pyramid, near-wall mask               [byte] */
   SR3D_PROF_PACK = 9,         /* weight packing / transforms and split-K reductions          [byte] */
   SR3D_PROF_EVAL = 10,        /* fused evaluation metrics                                    [byte] */
-  SR3D_PROF_FAMILIES = 11,
+  SR3D_PROF_HCONV = 11,       /* stride-1 conv on the split-f16 kernel (SR3D_SPLIT_F16=1)     [FLOP] */
+  SR3D_PROF_FAMILIES = 12,
   SR3D_PROF_DROPPED = 99      /* launches: records lost because the event pool was exhausted */
 };
 int sr3d_profile_enable(int on);
