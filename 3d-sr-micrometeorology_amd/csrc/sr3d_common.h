@@ -77,7 +77,7 @@ size_t sr3d_wino_image_floats(int rows, int K);
 int sr3d_wino_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                    const int* cbeg, float* image, hipStream_t st);
 int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st);
-// launch description of the split-f16 stride-1 conv (sr3d_hconv.hip, opt-in with SR3D_SPLIT_F16=1)
+// launch description of the split-f16 stride-1 conv (sr3d_hconv.hip)
 struct SrHconvParams {
   ChanCat in;          // K side (virtual concat)
   int K;               // input channels
@@ -99,7 +99,7 @@ struct SrHconvParams {
   int TZ_, TY_, TX_;
   int unsh_C, Cg;
 };
-bool sr3d_hconv_enabled();
+int sr3d_hconv_mode();   // SR3D_SPLIT_F16: 0 off, 1 auto (default), 2 always
 size_t sr3d_hconv_image_bytes(int rows, int K);
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                     const int* cbeg, void* image, hipStream_t st);

@@ -1,5 +1,6 @@
 // Stride-1 3x3x3 convolution (forward and input gradient) with fp32 operands split into two fp16 halves, on
-// v_mfma_f32_32x32x16_f16 -- OPT-IN (SR3D_SPLIT_F16=1), the fp32 Winograd kernel stays the default.
+// v_mfma_f32_32x32x16_f16.  Default for the layers that fill the chip (use_hconv in sr3d_igemm.hip); SR3D_SPLIT_F16=0
+// puts every stride-1 layer back on the fp32 Winograd kernel, =2 forces this kernel for every eligible layer.
 //
 // Why: gfx950's fp32 MFMA runs at 1/16 of the f16 rate.  An fp32 value scaled into [2^13, 2^14) splits EXACTLY into
 // hi = fp16(a) and lo = fp16(a - hi) with |a - hi - lo| <= 2^-22 |a|, and
@@ -15,13 +16,15 @@
 // any input, gradients of 1e-9 keep their 22 bits, elements 2^-14 below the maximum lose only what is below 2^-36 of
 // it.  The epilogue multiplies by 2^-(sa+sw).
 //
-// One 512-thread workgroup (alone on its CU): 64 (or 32) output rows x 4 x 4 x 32 voxels; wave w owns voxel rows
-// 2w, 2w+1 for all row tiles.  Chunk = 16 channels = K of one MFMA.
-//   halo      [part][channel half][voxel 6x6x34][8 ch] fp16 (80 KB): raw fp32 rows come in by buffer loads with
+// One 256-thread workgroup, TWO per CU (80 KB of LDS each): 64 (or 32) output rows x 2 x 4 x 32 voxels; wave w owns
+// voxel rows 2w, 2w+1 for all row tiles.  Chunk = 16 channels = K of one MFMA.  The two workgroups of a CU are
+// independent, so the barriers and the halo refill of one are covered by the MFMAs of the other (one 512-thread
+// workgroup per CU kept the matrix pipe 60 % busy: all eight waves met at the same barriers).
+//   halo      [part][channel half][voxel 4x6x34][8 ch] fp16 (56 KB): raw fp32 rows come in by buffer loads with
 //             hardware range checks one chunk ahead (registers), are scaled, split and written as 16-byte pieces;
 //             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
-//   weights   split + packed once per call: [row block][chunk][kz][ky,kx][part][row tile][64 lanes][8 ch]; one kz
-//             phase (36 KB) arrives by LDS-DMA while the previous one is multiplied (two buffers)
+//   weights   split + packed once per call: [row block][chunk][kz][ky][kx][part][row tile][64 lanes][8 ch]; one
+//             (kz, ky) phase (3 taps, 12 KB) arrives by LDS-DMA while the previous one is multiplied (two buffers)
 #include "sr3d_common.h"
 
 #include <limits.h>
@@ -29,24 +32,30 @@
 
 #include <atomic>
 
+#ifndef HCONV_ABL
+#define HCONV_ABL 0
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int HKC = 16;                        // channels per chunk
-constexpr int HHZ = 6, HHY = 6, HHX = 34;      // halo of the 4 x 4 x 32 voxel tile
-constexpr int HVOX = HHZ * HHY * HHX;          // 1224
-constexpr int HVP = 1280;                      // voxels per plane, padded to 20 waves
+constexpr int HHZ = 4, HHY = 6, HHX = 34;      // halo of the 2 x 4 x 32 voxel tile
+constexpr int HVOX = HHZ * HHY * HHX;          // 816
+constexpr int HNR = 7;                         // staging rounds: 2 waves per channel half x 7 x 64 voxels
+constexpr int HVP = 2 * HNR * 64;              // voxels per plane, padded (896)
 constexpr int HPLANE = HVP * 16;               // bytes of one (part, channel half) plane
-constexpr int HBYTES = 4 * HPLANE;             // 81920
-constexpr int HNT = 512;
+constexpr int HBYTES = 4 * HPLANE;             // 57344
+constexpr int HNT = 256;
+constexpr int HPH = 9;                         // weight phases per chunk: (kz, ky), 3 taps each
 template <int RT>
 struct HGeo {
-  static constexpr int PIECES = 9 * 2 * RT;    // 1 KB fragments of one kz phase
+  static constexpr int PIECES = 3 * 2 * RT;    // 1 KB fragments of one phase
   static constexpr int WPHASE = PIECES * 1024;
   static constexpr size_t LDS = HBYTES + 2 * (size_t)WPHASE;
 };
-static_assert(HGeo<2>::LDS <= 160 * 1024, "LDS budget");
+static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
 typedef __attribute__((address_space(3))) void* lds_p;
 
@@ -79,7 +88,7 @@ __device__ __forceinline__ void pin_scalar(T& x) {
 }
 
 template <int RT>
-__global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
+__global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   using G = HGeo<RT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Hs = lds;
@@ -87,6 +96,7 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < HNT / 64);
 
   // workgroup -> (row block, voxel tile); the row blocks of one tile run next to each other on one XCD
   int v;
@@ -102,20 +112,21 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
   const int tiy = blk % p.nty;
   const int tiz = blk / p.nty;
   const int b = blockIdx.y;
-  const int z0 = tiz * 4, y0 = tiy * 4, x0 = tix * 32;
+  const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
   const int chan_bytes = (int)(ZYX * 4);
 
   const int sa = scale_exp(*p.absmax_x), sw = scale_exp(*p.absmax_w);
-  const float in_mult = ldexpf(1.f, sa), out_mult = ldexpf(1.f, -(sa + sw));
+  // (sign: the accumulators alternate sign from chunk to chunk, see the chunk loop)
+  const float in_mult = ldexpf(1.f, sa), out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -(sa + sw));
 
-  // ---- staging geometry: this wave stages channel half `sh` of every chunk, voxel blocks r * 4 + (wave >> 1)
+  // ---- staging geometry: this wave stages channel half `sh` of every chunk, voxel blocks r * 2 + (wave >> 1)
   const int sh = wave & 1;
-  unsigned soff[5];   // byte offset inside a channel volume, 0xffffffff = zero padding
-  int swr[5];         // byte offset of the 16-byte piece inside a halo plane
+  unsigned soff[HNR];   // byte offset inside a channel volume, 0xffffffff = zero padding
+  int swr[HNR];         // byte offset of the 16-byte piece inside a halo plane
 #pragma unroll
-  for (int r = 0; r < 5; r++) {
-    const int e = (r * 4 + (wave >> 1)) * 64 + lane;
+  for (int r = 0; r < HNR; r++) {
+    const int e = (r * 2 + (wave >> 1)) * 64 + lane;
     const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
     const int hy = r2 / HHX, hx = r2 - hy * HHX;
     const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
     const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
     return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
   };
-  float raw[5][8];
+  float raw[HNR][8];
   auto load_raw = [&](const int chunk) {
     const int gc0 = chunk * HKC + sh * 8;      // wave-uniform
     const int first = gc0 < p.K ? gc0 : p.K - 1, last = gc0 + 7 < p.K ? gc0 + 7 : p.K - 1;
@@ -161,12 +172,12 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
     for (int c = 0; c < 8; c++) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase[c], 0, gc0 + c < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 5; r++) raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
+      for (int r = 0; r < HNR; r++) raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
     }
   };
   auto write_halo = [&]() {
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
+    for (int r = 0; r < HNR; r++) {
       h8 hi, lo;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
@@ -183,14 +194,13 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
   // global_load_lds form is a FLAT instruction that touches two address spaces, and while one is pending hipcc turns
   // every LDS wait into lgkmcnt(0) -- the register double-buffering of the fragments below would wait for the reads
   // it has just issued.)
-  const unsigned char* wblock = reinterpret_cast<const unsigned char*>(p.wimg) + (size_t)(p.nb_off + nblk) * p.nchunks * 3 * G::WPHASE;
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wblock, 0, p.nchunks * 3 * G::WPHASE, 0x00020000);
-  auto dma_w = [&](const int phase, unsigned char* W) {   // phase = chunk * 3 + kz
+  const unsigned char* wblock = reinterpret_cast<const unsigned char*>(p.wimg) + (size_t)(p.nb_off + nblk) * p.nchunks * HPH * G::WPHASE;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wblock, 0, p.nchunks * HPH * G::WPHASE, 0x00020000);
+  auto dma_w = [&](const int phase, unsigned char* W) {   // phase = chunk * 9 + kz * 3 + ky
 #pragma unroll
-    for (int ii = 0; ii < (G::PIECES + 7) / 8; ii++) {
-      const int i = wave + 8 * ii;
-      if (i < G::PIECES)
-        lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
+    for (int ii = 0; ii < (G::PIECES + 3) / 4; ii++) {
+      const int i = wave + 4 * ii;
+      if (i < G::PIECES) lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
     }
   };
 
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
   const int abase = lane * 16;
 
   // ---- prologue
-  const int nphases = p.nchunks * 3;
+  const int nphases = p.nchunks * HPH;
   dma_w(0, Ws);
   load_raw(0);
   write_halo();
@@ -223,18 +233,17 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
   h8 fa[2][2][RT], fb[2][2][2];   // [set][part][row tile], [set][part][voxel row]
   // (issued in two groups of 4: more than 15 LDS reads in flight overflow the lgkmcnt counter and the compiler then
   // waits for all of them)
-  auto frags_a = [&](const int set, const unsigned char* W, const int t) {
+  auto frags_a = [&](const int set, const unsigned char* W, const int kx) {
 #pragma unroll
     for (int part = 0; part < 2; part++)
 #pragma unroll
-      for (int i = 0; i < RT; i++) fa[set][part][i] = *reinterpret_cast<const h8*>(W + ((t * 2 + part) * RT + i) * 1024);
+      for (int i = 0; i < RT; i++) fa[set][part][i] = *reinterpret_cast<const h8*>(W + ((kx * 2 + part) * RT + i) * 1024);
   };
-  auto frags_b = [&](const int set, const unsigned char* Hk, const int t) {
-    const int toff = ((t / 3) * HHX + (t % 3)) * 16;
+  auto frags_b = [&](const int set, const unsigned char* Hk, const int kx) {
 #pragma unroll
     for (int part = 0; part < 2; part++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) fb[set][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + toff);
+      for (int j = 0; j < 2; j++) fb[set][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + kx * 16);
   };
   auto mfmas = [&](const int set, const int i) {   // row tile i
 #pragma unroll
@@ -244,10 +253,10 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][j], acc[i][j], 0, 0, 0);
     }
   };
-  h8 chi[5], clo[5];   // the next chunk's halo pieces, split during the last kz phase
+  h8 chi[HNR], clo[HNR];   // the next chunk's halo pieces
   auto convert = [&]() {
 #pragma unroll
-    for (int r = 0; r < 5; r++)
+    for (int r = 0; r < HNR; r++) {
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const float sc = raw[r][c] * in_mult;
@@ -255,35 +264,57 @@ __global__ __launch_bounds__(HNT) void hconv_kernel(const SrHconvParams p) {
         chi[r][c] = a;
         clo[r][c] = (_Float16)(sc - (float)a);
       }
+      asm volatile("" : "+v"(chi[r]), "+v"(clo[r]));   // here, between the MFMAs -- not sunk to the stores behind the barrier
+    }
   };
 
   int phase = 0;
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
-    for (int kz = 0; kz < 3; kz++, phase++) {
+    for (int kzy = 0; kzy < HPH; kzy++, phase++) {
       const unsigned char* W = Ws + (phase & 1) * G::WPHASE + abase;
-      if (phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
-      const unsigned char* Hk = Hs + kz * (HHY * HHX * 16);
+      // split the next chunk's rows (they landed before the barrier of phase 1).  Before this phase's DMA is issued:
+      // hipcc does not see the hand-written waits and guards the first use of `raw` with its own vmcnt(0)
+      if (HCONV_ABL != 1 && kzy == 2) convert();
+      __builtin_amdgcn_sched_barrier(0);
+      if (HCONV_ABL != 2 && phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
+      __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
+      if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+      const unsigned char* Hk = Hs + ((kzy / 3) * HHY + (kzy % 3)) * (HHX * 16);
       frags_a(0, W, 0);
       frags_b(0, Hk, 0);
-      if (kz == 2) convert();   // (the raw rows landed before the barrier of phase 0)
 #pragma unroll
-      for (int t = 0; t < 9; t++) {
-        if (t + 1 < 9) frags_a((t + 1) & 1, W, t + 1);
+      for (int kx = 0; kx < 3; kx++) {
+        if (HCONV_ABL != 4 && kx + 1 < 3) frags_a((kx + 1) & 1, W, kx + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(t & 1, 0);
+        mfmas(HCONV_ABL == 4 ? 0 : (kx & 1), 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < 9) frags_b((t + 1) & 1, Hk, t + 1);
+        if (HCONV_ABL != 4 && kx + 1 < 3) frags_b((kx + 1) & 1, Hk, kx + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (RT == 2) mfmas(t & 1, 1);
+        if constexpr (RT == 2) mfmas(HCONV_ABL == 4 ? 0 : (kx & 1), 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // the next phase's weights (issued above, BEFORE the raw rows) have landed; in phase 0 the 8 * HNR raw-row
+      // loads of the next chunk stay in flight
+      if (kzy == 0)
+        asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
     }
-    if (chunk + 1 < p.nchunks) {
+    if (HCONV_ABL != 1 && chunk + 1 < p.nchunks) {
+      // The f16 MFMA truncates inside its adder tree: every accumulation step leaves a tiny NEGATIVE error whatever the
+      // sign of the sum (measured: mean error -5e-7 of the output rms at K = 1032, against 3e-10 for the fp32 MFMA; the
+      // normwise error is the same).  A bias adds up coherently in sums over a million voxels (bias gradients were
+      // 5e-5 off).  So the packed weights alternate sign from chunk to chunk and the accumulators are negated in
+      // between: the result is unchanged and the truncation errors of successive chunks cancel.
 #pragma unroll
-      for (int r = 0; r < 5; r++) {
+      for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] = -acc[i][j][r];
+#pragma unroll
+      for (int r = 0; r < HNR; r++) {
         *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
         *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
       }
@@ -438,7 +469,7 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
           val = w[(long long)k * kstride + tapidx];
         }
       }
-      const float s = val * w_mult;
+      const float s = val * ((chunk & 1) ? -w_mult : w_mult);   // alternating sign: see the kernel's chunk loop
       const _Float16 a = (_Float16)s;
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
@@ -486,16 +517,18 @@ inline void row_split(int rows, int* n2, int* n1) {   // 64-row blocks, and one 
 
 }  // namespace
 
-bool sr3d_hconv_enabled() {
-  const char* e = getenv("SR3D_SPLIT_F16");   // read per call: tests and tools switch it at run time
-  return e != nullptr && atoi(e) != 0;
+// SR3D_SPLIT_F16: 0 = off (fp32 Winograd everywhere), 1 / unset = on where the launch fills the chip, 2 = on for every
+// eligible layer whatever its size (tests).  Read per call: tests and tools switch it at run time.
+int sr3d_hconv_mode() {
+  const char* e = getenv("SR3D_SPLIT_F16");
+  return e == nullptr ? 1 : atoi(e);
 }
 
 // header (64 bytes: max |w|) + region A (64-row blocks) + region B (one 32-row block)
 size_t sr3d_hconv_image_bytes(int rows, int K) {
   int n2, n1;
   row_split(rows, &n2, &n1);
-  return 64 + (size_t)ceil_div(K, HKC) * 3 * ((size_t)n2 * HGeo<2>::WPHASE + (size_t)n1 * HGeo<1>::WPHASE);
+  return 64 + (size_t)ceil_div(K, HKC) * HPH * ((size_t)n2 * HGeo<2>::WPHASE + (size_t)n1 * HGeo<1>::WPHASE);
 }
 
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
@@ -520,7 +553,7 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
     if (p.nblk == 0) continue;
     p.RT = region == 0 ? 2 : 1;
     p.n_off = region == 0 ? 0 : n2 * 64;
-    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * 3 * (HGeo<2>::WPHASE / 2));
+    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * HPH * (HGeo<2>::WPHASE / 2));
     const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(hconv_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -549,7 +582,7 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st
   p.absmax_x = (const float*)slot;
   p.absmax_w = (const float*)image;
   p.wimg = (const unsigned char*)image + 64;
-  p.ntz = ceil_div(p.Z, 4), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
+  p.ntz = ceil_div(p.Z, 2), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
   p.nchunks = ceil_div(p.K, HKC);
   int n2, n1;
   row_split(p.N, &n2, &n1);
@@ -574,7 +607,7 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st
     // region B: its blocks are 32 rows; express the offsets in the kernel's own units
     SrHconvParams q = p;
     q.nblk = 1, q.nb_off = 0;
-    q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * 3 * HGeo<2>::WPHASE;
+    q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * HPH * HGeo<2>::WPHASE;
     q.n_off = p.n_off + n2 * 64;
     hipLaunchKernelGGL(hconv_kernel<1>, dim3((unsigned)nsp, B), dim3(HNT), HGeo<1>::LDS, st, q);
   }

@@ -442,9 +442,15 @@ inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
 inline bool use_wino(const sr3d_conv_desc_t* d) {
   return d->stride == 1 && sr3d_wino_enabled() && d->Cin <= SR3D_WINO_MAX_K && d->Cout <= SR3D_WINO_MAX_K;
 }
-// opt-in: stride-1 convolutions with >= 32 GEMM-K channels on the split-f16 kernel (sr3d_hconv.hip)
+// Stride-1 convolutions with >= 32 GEMM-K channels run on the split-f16 kernel (sr3d_hconv.hip; SR3D_SPLIT_F16=0 turns
+// it off, =2 forces it) when the launch fills the chip: its 2 x 4 x 32-voxel workgroups come two per CU, and on the small grids of
+// U-Net levels 3-4 the Winograd kernel with its one-tile workgroups is the faster one (measured: up4.convs 0.68 vs 0.89 ms).
 inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
-  return d->stride == 1 && sr3d_hconv_enabled() && K >= 32 && rows >= 16;
+  const int mode = sr3d_hconv_mode();
+  if (d->stride != 1 || K < 32 || rows < 16 || mode == 0) return false;
+  if (mode == 2) return true;
+  const long long wgs = (long long)d->B * ceil_div(d->Z, 2) * ceil_div(d->Y, 4) * ceil_div(d->X, 32) * ceil_div(rows, 64);
+  return wgs >= 448;
 }
 inline int hconv_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 64 * ((d->Cout + 31) / 32) : d->Cout;

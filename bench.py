@@ -37,13 +37,17 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic work per HR voxel per training step, default.yml widths
 FLOP_PER_VOXEL = 8_486_693
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_f16: 32 cycles per SIMD)
+# what tools/mfma_rate.hip sustains for 100 ms with register operands only: the f16 MFMA loop runs into the power limit
+# and the shader clock settles at 1.645 GHz (fp32 MFMA: 152 TFLOP/s at 2.33 GHz)
+F16_MFMA_SUSTAINED_TFLOPS = 1651.0
 # HBM traffic of the dominant kernel family per launch, from separate rocprofv3 --pmc passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass; FETCH_SIZE doubled as the guide prescribes for gfx950)
-TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")]
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 BYTES_PER_VOXEL = 11_586       # compulsory fwd+bwd activation traffic per HR voxel, fp32
 FAMILIES = {"igemm_s1": 0, "igemm_s2": 1, "igemm_bwd_s2": 2, "wgrad": 3, "loss": 4, "act_bwd": 5, "bias_grad": 6,
-            "adam": 7, "data": 8, "pack_reduce": 9}
+            "adam": 7, "data": 8, "pack_reduce": 9, "hconv": 11}
 
 DEFAULT_CONFIG = {
     "data": {"stds": [8.40, 14.40, 21.60, 7.00]},
@@ -244,26 +248,56 @@ def main():
         second = measure(sr3d_amd, L, dev, rank, world, use_dist, sb, sl, args.lr_grid, min(args.steps, 3), 1)
         second["batch"], second["loss_name"] = sb, sl
 
+    fp32_only = None   # the same configuration with every stride-1 layer back on the fp32 Winograd kernel
+    if not args.no_secondary and not args.graph and os.environ.get("SR3D_SPLIT_F16", "1") != "0":
+        prev = os.environ.get("SR3D_SPLIT_F16")
+        os.environ["SR3D_SPLIT_F16"] = "0"
+        fp32_only = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, min(args.steps, 5), 1)
+        if prev is None:
+            del os.environ["SR3D_SPLIT_F16"]
+        else:
+            os.environ["SR3D_SPLIT_F16"] = prev
+
     if rank == 0:
         elapsed, prof, hr = m["elapsed"], m["prof"], m["hr"]
         value = m["voxels_per_step"] * args.steps / elapsed
-        dom = prof["igemm_s1"]
-        algo = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         wino = os.environ.get("SR3D_WINOGRAD", "1") != "0"
-        executed = algo / (2.25 if wino else 1.0)
+        split = prof["hconv"]["ms"] > prof["igemm_s1"]["ms"]   # the split-f16 kernel carries the stride-1 layers
+        dom_key = "hconv" if split else "igemm_s1"
+        dom = prof[dom_key]
+        algo = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        # MFMA FLOPs the kernel executes per algorithmic FLOP: 3 f16 products per fp32 product (split-f16, direct),
+        # 1 / 2.25 (fp32 Winograd F(2x2,3x3) in (y,x)), 1 (direct fp32)
+        executed = algo * 3.0 if split else algo / (2.25 if wino else 1.0)
+        peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         traffic = None
         tj = next((f for f in TRAFFIC_JSONS if os.path.exists(f)), None)
         if tj and batch == 1 and loss_name == "l1" and wino:
-            t = json.load(open(tj)).get("igemm_s1")
+            t = json.load(open(tj)).get(dom_key)
             if t:
                 traffic = {"hbm_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"] + t["write_bytes_per_launch"],
                            "fetch_bytes_per_launch": t["fetch_bytes_per_launch_x2_gfx950"],
                            "write_bytes_per_launch": t["write_bytes_per_launch"],
                            "kernel_launches_profiled": t["launches_profiled"],
                            "source": os.path.relpath(tj, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        if split:
+            kernel_desc = ("stride-1 conv forward + input gradient on hconv_kernel: direct implicit GEMM on "
+                           "v_mfma_f32_32x32x16_f16, fp32 operands split into two fp16 halves (3 products), fp32 accumulate")
+            note = ("achieved = f16 MFMA FLOPs the kernel EXECUTES per second = 3 x algorithmic FLOPs of the 3x3x3 "
+                    "convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d); channel padding to 16 not counted) / kernel "
+                    "time from HIP events; peak = dense f16 MFMA at 2.4 GHz.  The f16 MFMA is POWER-bound on this part: "
+                    f"tools/mfma_rate.hip sustains {F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s (register operands only, 100 ms, "
+                    "clock settling at 1.645 GHz) -- frac_of_sustained is against that")
+        else:
+            kernel_desc = ("stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
+                           "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)")
+            note = ("achieved = fp32 MFMA FLOPs the kernel EXECUTES per second = algorithmic FLOPs of the "
+                    "3x3x3 convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d)) / 2.25 (Winograd "
+                    "F(2x2,3x3) in (y,x) needs 48 instead of 108 products per 2x2x1 outputs) / kernel time "
+                    "from HIP events; frac = matrix-pipe utilisation against the fp32 MFMA peak")
         conv = {k: {"ms_per_step": prof[k]["ms"] / args.steps, "launches_per_step": prof[k]["launches"] / args.steps,
                     "algorithmic_tflops": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e12 if prof[k]["ms"] > 0 else 0.0)}
-                for k in ("igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")}
+                for k in ("hconv", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")}
         hbm = {k: {"ms_per_step": prof[k]["ms"] / args.steps, "launches_per_step": prof[k]["launches"] / args.steps,
                    "gbytes_per_s": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9 if prof[k]["ms"] > 0 else 0.0),
                    "frac_of_hbm_peak": (prof[k]["work"] / (prof[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -280,23 +314,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32",
+            "dtype": ("fp32 (storage, accumulation and results; stride-1 conv products as 3 f16 MFMAs on 2-way split fp32 "
+                      "operands, error 2^-22 per operand, every parity test at 1e-5; SR3D_SPLIT_F16=0: fp32 MFMA only)"
+                      if split else "fp32"),
             "data": "synthetic",
             "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world) +
                        (" [hipGraph replay]" if args.graph else ""),
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": executed, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": executed / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
-                                   "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)",
-                         "note": "achieved = fp32 MFMA FLOPs the kernel EXECUTES per second = algorithmic FLOPs of the "
-                                 "3x3x3 convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d)) / 2.25 (Winograd "
-                                 "F(2x2,3x3) in (y,x) needs 48 instead of 108 products per 2x2x1 outputs) / kernel time "
-                                 "from HIP events; frac = matrix-pipe utilisation against the fp32 MFMA peak",
+            "roofline": {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s",
+                         "frac": executed / peak, "traffic": traffic,
+                         "kernel": kernel_desc,
+                         "note": note,
                          "algorithmic_tflops": algo,
                          "launches_per_step": dom["launches"] / args.steps,
-                         "kernel_ms_per_step": dom["ms"] / args.steps},
+                         "kernel_ms_per_step": dom["ms"] / args.steps,
+                         **({"frac_of_sustained": executed / F16_MFMA_SUSTAINED_TFLOPS} if split else {})},
             "hbm_frac": value / (world * HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL),
             "hbm_note": f"voxels/s against the HBM-only ceiling {HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL / 1e6:.0f} M voxels/s/GPU "
                         f"(8 TB/s / {BYTES_PER_VOXEL} B of compulsory activation traffic per voxel); the step is "
@@ -318,6 +351,15 @@ def main():
                         "loss_kernels_ms_per_step": sp["loss"]["ms"] / min(args.steps, 3),
                         "loss_kernels_gbytes_per_s": (sp["loss"]["work"] / (sp["loss"]["ms"] * 1e-3) / 1e9
                                                       if sp["loss"]["ms"] > 0 else 0.0)}
+        if fp32_only is not None:
+            n5 = min(args.steps, 5)
+            fd = fp32_only["prof"]["igemm_s1"]
+            out["fp32_mfma_only"] = {"note": "same workload with SR3D_SPLIT_F16=0 (fp32 Winograd kernel for every stride-1 layer)",
+                                     "value": fp32_only["voxels_per_step"] * n5 / fp32_only["elapsed"], "unit": "HR voxels/s",
+                                     "steps": n5, "warmup": 1, "ms_per_step": fp32_only["elapsed"] / n5 * 1e3,
+                                     "loss": fp32_only["loss"],
+                                     "wino_kernel_frac_of_fp32_mfma_peak": (fd["work"] / (fd["ms"] * 1e-3) / 1e12 / 2.25 /
+                                                                            FP32_MFMA_PEAK_TFLOPS if fd["ms"] > 0 else 0.0)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["cfg"])
         print(json.dumps(out), flush=True)

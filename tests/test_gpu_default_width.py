@@ -115,7 +115,8 @@ def test_whole_model_default_widths(eng, fname):
                 bad.append((row["param"], a32, row))
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    tag = os.environ.get("SR3D_WINOGRAD", "1") + os.environ.get("SR3D_WINOGRAD_WGRAD", "1")
+    tag = os.environ.get("SR3D_WINOGRAD", "1") + os.environ.get("SR3D_WINOGRAD_WGRAD", "1") + \
+        ("_split" if os.environ.get("SR3D_SPLIT_F16") == "2" else "")
     with open(os.path.join(out_dir, f"default_width_grad_errors_{fname[:-4]}_{tag}.json"), "w") as f:
         json.dump(rows, f, indent=1)
     print(f"{fname}: free decisions: worst vs fp32 oracle {max(r['orc32'] for r in rows):.2e}, vs fp64 oracle "
@@ -275,10 +276,12 @@ def test_winograd_ragged_tiles_with_activation(eng, shape, cin, cout, gated, act
         assert relerr(bgd.grad, bgr.grad) < TOL
 
 
-@pytest.mark.parametrize("env", [{"SR3D_WINOGRAD": "0"}, {"SR3D_WINOGRAD_WGRAD": "0"}])
+@pytest.mark.parametrize("env", [{"SR3D_WINOGRAD": "0"}, {"SR3D_WINOGRAD_WGRAD": "0"}, {"SR3D_SPLIT_F16": "2"}])
 def test_default_widths_on_the_direct_kernels(env):
-    """kernel families are selected once per process from the environment: run this file again under each setting"""
-    if os.environ.get("SR3D_WINOGRAD") == "0" or os.environ.get("SR3D_WINOGRAD_WGRAD") == "0":
+    """kernel families are selected from the environment: run this file again under each setting (SR3D_SPLIT_F16=2: the
+    split-f16 kernel for every eligible stride-1 layer, also at this small grid)"""
+    if os.environ.get("SR3D_WINOGRAD") == "0" or os.environ.get("SR3D_WINOGRAD_WGRAD") == "0" or \
+            os.environ.get("SR3D_SPLIT_F16") == "2":
         pytest.skip("already inside the re-run")
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",

@@ -257,10 +257,12 @@ def test_errors_are_loud(eng):
         eng.model.custom_conv.MyConvWithAct2(3, 2, 3, padding=1, conv_mode="p_conv")
 
 
-@pytest.mark.parametrize("env", [{"SR3D_WINOGRAD": "0"}, {"SR3D_WINOGRAD_WGRAD": "0"}])
+@pytest.mark.parametrize("env", [{"SR3D_WINOGRAD": "0"}, {"SR3D_WINOGRAD_WGRAD": "0"}, {"SR3D_SPLIT_F16": "2"}])
 def test_alternative_kernel_paths_in_subprocess(env):
     """the direct stride-1 kernels (SR3D_WINOGRAD=0) and the direct stride-1 weight gradient (SR3D_WINOGRAD_WGRAD=0) are selected
-    once per process from the environment: run the conv / model parity tests again under each setting"""
+    once per process from the environment: run the conv / model parity tests again under each setting.  SR3D_SPLIT_F16=2
+    puts every eligible stride-1 layer on the split-f16 kernel whatever its size (by default only launches that fill the
+    chip take it, i.e. none of the small golden cases)"""
     import os
     import subprocess
     import sys

@@ -1,0 +1,126 @@
+"""The split-f16 stride-1 convolution kernel (csrc/sr3d_hconv.hip): fp32 operands as two fp16 halves, three f16 MFMAs
+per product group, fp32 accumulation -- against fp64 references (pytest -m gpu, on the MI355X box).
+
+SR3D_SPLIT_F16=2 forces the kernel for every eligible layer (by default only launches that fill the chip take it);
+the switch is read per call, so the fixtures flip it in-process.  Tolerance: 1e-5 normwise as everywhere else; the
+measured error is ~4e-7, that of the fp32 MFMA kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sr3d_amd
+    return sr3d_amd
+
+
+@pytest.fixture()
+def forced(monkeypatch):
+    monkeypatch.setenv("SR3D_SPLIT_F16", "2")
+
+
+def _ref_and_inputs(cs, cout, grid, kind, scale, seed, batch=2):
+    g = torch.Generator().manual_seed(seed)
+    Z, Y, X = grid
+    xs = [((torch.rand(batch, c, Z, Y, X, generator=g) - 0.3) * scale).double().requires_grad_(c > 1) for c in cs]
+    cin = sum(cs)
+    wf = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).double().requires_grad_(True)
+    wg = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).double().requires_grad_(True)
+    bias = (torch.randn(cout, generator=g) * 0.1 * scale).double().requires_grad_(True)
+    x = torch.cat(xs, 1)
+    if kind == "gated":
+        pre_f, pre_g = F.conv3d(x, wf, None, padding=1), F.conv3d(x, wg, bias, padding=1)
+        ref = torch.sigmoid(pre_g) * torch.relu(pre_f)
+    else:
+        pre_f = F.conv3d(x, wf, bias, padding=1)
+        ref = F.leaky_relu(pre_f, 0.01)
+    gy = (torch.rand(ref.shape, generator=g) - 0.5).double()
+    # keep the comparison on the smooth part: no gradient through pre-activations within 1e-4 of the kink
+    gy = gy * (pre_f.detach().abs() > 1e-4 * scale)
+    ref.backward(gy)
+    return xs, wf, wg, bias, ref, gy
+
+
+# (source channels, Cout, grid, kind, scale): ragged grids, K not a multiple of 16, a concat boundary inside a chunk,
+# <= 32-row and 33-row row blocks, 1 .. 4 remainder rows, tiny and large magnitudes (the per-call power-of-two scaling)
+CASES = [
+    ([64], 64, (8, 16, 64), "plain", 1.0),
+    ([64, 1, 65], 48, (6, 10, 40), "plain", 1.0),
+    ([33], 72, (5, 7, 33), "plain", 1.0),
+    ([40], 130, (3, 9, 70), "plain", 300.0),
+    ([64], 64, (4, 8, 32), "plain", 1e-7),
+    ([128], 32, (4, 8, 32), "gated", 1.0),
+    ([36, 1], 40, (5, 6, 35), "gated", 1.0),
+]
+
+
+@pytest.mark.parametrize("cs,cout,grid,kind,scale", CASES)
+def test_split_f16_layers_vs_fp64(eng, forced, cs, cout, grid, kind, scale):
+    xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, scale, seed=sum(cs) + cout)
+    dev = lambda t: t.detach().float().to(DEV)   # noqa: E731
+    xd = [dev(x).requires_grad_(x.requires_grad) for x in xs]
+    wfd, wgd, bd = dev(wf).requires_grad_(True), dev(wg).requires_grad_(True), dev(bias).requires_grad_(True)
+    if kind == "gated":
+        y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act="relu", stride=1)
+    else:
+        y = eng.ops.conv3d_act(xd, wfd, bd, act="lrelu", stride=1)
+    assert relerr(y, ref) < TOL
+    y.backward(dev(gy))
+    for a, b in zip(xd, xs):
+        if b.requires_grad:
+            assert relerr(a.grad, b.grad) < TOL
+    assert relerr(wfd.grad, wf.grad) < TOL and relerr(bd.grad, bias.grad) < TOL
+    if kind == "gated":
+        assert relerr(wgd.grad, wg.grad) < TOL
+
+
+def test_split_f16_unshuffle_epilogue_matches_the_fp32_kernel(eng, monkeypatch):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(2, 33, 5, 7, 33, generator=g) - 0.5).to(DEV)
+    w = (torch.randn(72, 33, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    b = (torch.randn(72, generator=g) * 0.1).to(DEV)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SR3D_SPLIT_F16", mode)
+        with torch.no_grad():
+            out[mode] = eng.ops.conv3d_act([x], w, b, act="lrelu", unshuffle=True)
+    assert out["2"].shape == (2, 9, 10, 14, 66)
+    assert relerr(out["2"], out["0"]) < 2e-6
+
+
+def test_split_f16_has_no_accumulation_bias(eng, forced):
+    """The f16 MFMA truncates inside its adder tree: accumulated naively, every output carries a small NEGATIVE error
+    (-5e-7 of the output rms at K = 1032) that adds up coherently in sums over voxels (bias gradients).  The kernel
+    alternates the sign of accumulator and weights from chunk to chunk; what is left is below 5e-8 of the rms."""
+    g = torch.Generator().manual_seed(11)
+    for K, N, grid in ((1032, 129, (4, 8, 32)), (257, 264, (2, 4, 32))):
+        x = torch.randn(1, K, *grid, generator=g)
+        w = torch.randn(N, K, 3, 3, 3, generator=g) * (2.0 / (27 * K)) ** 0.5
+        ref = F.conv3d(x.double(), w.double(), None, padding=1)
+        with torch.no_grad():
+            y = eng.ops.conv3d_act([x.to(DEV)], w.to(DEV), None, act=None, stride=1)
+        err = y.cpu().double() - ref
+        assert relerr(y, ref) < TOL
+        assert abs(err.mean().item()) < 5e-8 * ref.std().item(), (K, err.mean().item() / ref.std().item())
+
+
+def test_default_mode_takes_the_split_kernel_only_on_chip_filling_launches(eng, monkeypatch):
+    """same numbers either way (to the kernels' 1e-6), and the small launch must not depend on the switch being 1 or 0"""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(1, 64, 4, 8, 32, generator=g) - 0.5).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("SR3D_SPLIT_F16", mode)
+        with torch.no_grad():
+            out[mode] = eng.ops.conv3d_act([x], w, None, act=None, stride=1)
+    assert torch.equal(out["0"], out["1"])            # 16 workgroups: the Winograd kernel in both
+    assert not torch.equal(out["0"], out["2"]) and relerr(out["2"], out["0"]) < 2e-6

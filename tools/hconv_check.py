@@ -30,6 +30,28 @@ def main():
         ([64], 64, (8, 16, 64), "p", 1.0), ([64, 1, 65], 48, (6, 10, 40), "p", 1.0), ([128], 128, (4, 8, 32), "g", 1.0),
         ([33], 72, (5, 7, 33), "u", 1.0), ([64], 64, (8, 16, 64), "p", 1e-7), ([40], 130, (9, 9, 70), "p", 300.0),
     ]
+    if len(sys.argv) > 1 and sys.argv[1] == "deep":   # large GEMM-K: error against fp64, forward and input gradient
+        cases = [([1032], 129, (4, 8, 32), "p", 1.0), ([257], 2056, (2, 4, 32), "p", 1.0), ([514], 256, (4, 8, 32), "p", 1.0)]
+        for cs, cout, (Z, Y, X), kind, sc in cases:
+            x = (torch.randn(1, cs[0], Z, Y, X, device=dev)).requires_grad_(True)
+            w = (torch.randn(cout, cs[0], 3, 3, 3, device=dev) * (2.0 / (27 * cs[0])) ** 0.5).requires_grad_(True)
+            gy = torch.randn(1, cout, Z, Y, X, device=dev)
+            x64, w64 = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+            y64 = F.conv3d(x64, w64, None, padding=1)
+            y64.backward(gy.double().cpu())
+            for mode in ("0", "1"):
+                os.environ["SR3D_SPLIT_F16"] = mode
+                x.grad = None
+                w.grad = None
+                y = ops.conv3d_act([x], w, None, act=None, stride=1)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                d = (y.detach().cpu().double() - y64.detach())
+                dg = (x.grad.cpu().double() - x64.grad)
+                print(f"K={cs[0]} N={cout} mode={mode}: fwd rel {rel(y.cpu(), y64.detach()):.2e} mean-err/rms {d.mean().item() / y64.std().item():.2e}"
+                      f" | dgrad rel {rel(x.grad.cpu(), x64.grad):.2e} mean-err/rms {dg.mean().item() / x64.grad.std().item():.2e}")
+        os.environ["SR3D_SPLIT_F16"] = "0"
+        return
     for cs, cout, (Z, Y, X), kind, sc in cases:
         srcs = [((torch.rand(2, c, Z, Y, X, device=dev) - 0.3) * sc).requires_grad_(c > 1) for c in cs]
         cin = sum(cs)
