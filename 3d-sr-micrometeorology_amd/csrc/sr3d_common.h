@@ -85,7 +85,6 @@ struct SrHconvParams {
   int ntz, nty, ntx, nblk, nchunks;   // set by sr3d_hconv_launch
   int nb_off;          // first row block of this launch inside its image region
   const void* wimg;    // split + packed weights (region base)
-  const float* absmax_x;   // device: max |x| over the K-side tensors of this call
   const float* absmax_w;   // device: max |w| (header of the packed image)
   int N;               // GEMM rows (gated: 64 per 32 channels)
   int n_off;

@@ -11,10 +11,13 @@
 // 16 points x 32 tiles are 164 KB of LDS), so this is a DIRECT implicit GEMM: 81 f16 MFMAs per (32 rows x 32 voxels
 // x 16 channels) = 2592 cycles, against 6144 for fp32 Winograd.
 //
-// Scaling: per launch, in_mult = 2^sa and w_mult = 2^sw are exact powers of two taken from max|x| (one HBM pass,
-// absmax_kernel) and max|w| (at packing time) so that the largest element lands in [2^13, 2^14): no fp16 overflow for
-// any input, gradients of 1e-9 keep their 22 bits, elements 2^-14 below the maximum lose only what is below 2^-36 of
-// it.  The epilogue multiplies by 2^-(sa+sw).
+// Scaling (block floating point): every workgroup scales each 16-channel chunk of ITS halo tile by an exact power of
+// two taken from the largest magnitude it has seen so far in its tile (wave maxima meet in LDS at a barrier that is
+// there anyway), so that this magnitude lands in [2^13, 2^14): no fp16 overflow for any input, gradients of 1e-9 keep
+// their 22 bits, elements 2^-14 below the local maximum lose only what is below 2^-36 of it.  When a larger chunk
+// arrives the accumulators are rescaled by the (exact) ratio.  The weights carry one power of two per layer from
+// max|w|, found at packing time.  The epilogue multiplies by 2^-(sx+sw).  (The first version took max|x| over the
+// whole tensor in a separate HBM pass: 10 ms per training step.)
 //
 // One 256-thread workgroup, TWO per CU (80 KB of LDS each): 64 (or 32) output rows x 2 x 4 x 32 voxels; wave w owns
 // voxel rows 2w, 2w+1 for all row tiles.  Chunk = 16 channels = K of one MFMA.  The two workgroups of a CU are
@@ -30,7 +33,6 @@
 #include <limits.h>
 #include <stdlib.h>
 
-#include <atomic>
 
 #ifndef HCONV_ABL
 #define HCONV_ABL 0
@@ -65,12 +67,15 @@ __device__ __forceinline__ float hact(float v, int act) {
   return v;
 }
 
-// exponent s with amax * 2^s in [2^13, 2^14) (0 for amax = 0 or not finite)
+// exponent s with amax * 2^s in [2^13, 2^14); kScaleNone for amax = 0 ("no opinion"), 0 for inf / NaN
+constexpr int kScaleNone = 120;
 __device__ __forceinline__ int scale_exp(float amax) {
-  if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+  if (amax != amax || amax > 3.0e38f) return 0;
+  if (!(amax > 0.f)) return kScaleNone;
   int e;
   frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
-  return 14 - e;
+  const int s = 14 - e;
+  return s > kScaleNone ? kScaleNone : s;
 }
 
 // 16 bytes per lane, global -> LDS, buffer form.  (Device pass only: the host pass of hipcc rejects the 16-byte size
@@ -116,9 +121,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const long long ZYX = (long long)p.Z * p.Y * p.X;
   const int chan_bytes = (int)(ZYX * 4);
 
-  const int sa = scale_exp(*p.absmax_x), sw = scale_exp(*p.absmax_w);
-  // (sign: the accumulators alternate sign from chunk to chunk, see the chunk loop)
-  const float in_mult = ldexpf(1.f, sa), out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -(sa + sw));
+  int sw = scale_exp(*p.absmax_w);
+  if (sw == kScaleNone) sw = 0;
+  // exchange slots for the wave maxima [chunk parity][wave]: in the padding behind the 816 voxels of halo plane 0
+  float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
 
   // ---- staging geometry: this wave stages channel half `sh` of every chunk, voxel blocks r * 2 + (wave >> 1)
   const int sh = wave & 1;
@@ -175,19 +181,44 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       for (int r = 0; r < HNR; r++) raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
     }
   };
+  // largest |value| among this wave's rows of the chunk in `raw` -> its exchange slot
+  auto publish_max = [&](const int parity) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < HNR; r++)
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) xmax[parity * 4 + wave] = m;
+  };
+  // running scale exponent: the largest chunk magnitude seen so far decides (kScaleNone until a non-zero chunk came)
+  auto next_scale = [&](const int parity, const int s_run) {
+    const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
+    const int s_c = __builtin_amdgcn_readfirstlane(scale_exp(m));
+    return s_c < s_run ? s_c : s_run;
+  };
+  h8 chi[HNR], clo[HNR];   // halo pieces of the next chunk, split
+  auto convert = [&](const float in_mult) {
+#pragma unroll
+    for (int r = 0; r < HNR; r++) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float sc = raw[r][c] * in_mult;
+        const _Float16 a = (_Float16)sc;
+        chi[r][c] = a;
+        clo[r][c] = (_Float16)(sc - (float)a);
+      }
+      asm volatile("" : "+v"(chi[r]), "+v"(clo[r]));   // here, between the MFMAs -- not sunk to the stores behind the barrier
+      __builtin_amdgcn_sched_barrier(0);               // one round at a time: its temporaries die before the next starts
+    }
+  };
   auto write_halo = [&]() {
 #pragma unroll
     for (int r = 0; r < HNR; r++) {
-      h8 hi, lo;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const float s = raw[r][c] * in_mult;
-        const _Float16 a = (_Float16)s;
-        hi[c] = a;
-        lo[c] = (_Float16)(s - (float)a);
-      }
-      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;
-      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
+      if (r == HNR - 1 && swr[r] >= HVOX * 16) continue;   // padding voxels: the exchange slots live there
+      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
+      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
     }
   };
   // one kz phase of the packed weights: PIECES contiguous 1 KB fragments, LDS-DMA.  (The buffer form on purpose: the
@@ -225,9 +256,15 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const int nphases = p.nchunks * HPH;
   dma_w(0, Ws);
   load_raw(0);
-  write_halo();
+  publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  int s_run = next_scale(0, kScaleNone);   // exponent of the scale the accumulators are in
+  convert(ldexpf(1.f, s_run));
+  write_halo();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int s_next = s_run;
 
   // fragments are double-buffered in registers: the reads of tap t+1 are issued before the MFMAs of tap t
   h8 fa[2][2][RT], fb[2][2][2];   // [set][part][row tile], [set][part][voxel row]
@@ -253,28 +290,20 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][j], acc[i][j], 0, 0, 0);
     }
   };
-  h8 chi[HNR], clo[HNR];   // the next chunk's halo pieces
-  auto convert = [&]() {
-#pragma unroll
-    for (int r = 0; r < HNR; r++) {
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const float sc = raw[r][c] * in_mult;
-        const _Float16 a = (_Float16)sc;
-        chi[r][c] = a;
-        clo[r][c] = (_Float16)(sc - (float)a);
-      }
-      asm volatile("" : "+v"(chi[r]), "+v"(clo[r]));   // here, between the MFMAs -- not sunk to the stores behind the barrier
-    }
-  };
-
   int phase = 0;
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
+#pragma unroll   // (rolled, the next chunk's raw rows and their split form are both live in every phase: spills)
     for (int kzy = 0; kzy < HPH; kzy++, phase++) {
       const unsigned char* W = Ws + (phase & 1) * G::WPHASE + abase;
-      // split the next chunk's rows (they landed before the barrier of phase 1).  Before this phase's DMA is issued:
-      // hipcc does not see the hand-written waits and guards the first use of `raw` with its own vmcnt(0)
-      if (HCONV_ABL != 1 && kzy == 2) convert();
+      // Phase 1: this wave's share of the next chunk has landed (issued in phase 0): publish its largest magnitude.
+      // Phase 2 (behind the barrier of phase 1): all four maxima -> scale of the next chunk; split its rows.  Both before
+      // this phase's DMA is issued: hipcc does not see the hand-written waits and guards the first use of `raw` with its
+      // own vmcnt(0).
+      if (HCONV_ABL != 1 && kzy == 1) publish_max((chunk + 1) & 1);
+      if (HCONV_ABL != 1 && kzy == 2) {
+        s_next = next_scale((chunk + 1) & 1, s_run);
+        convert(ldexpf(1.f, s_next));
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (HCONV_ABL != 2 && phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
@@ -306,24 +335,25 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       // sign of the sum (measured: mean error -5e-7 of the output rms at K = 1032, against 3e-10 for the fp32 MFMA; the
       // normwise error is the same).  A bias adds up coherently in sums over a million voxels (bias gradients were
       // 5e-5 off).  So the packed weights alternate sign from chunk to chunk and the accumulators are negated in
-      // between: the result is unchanged and the truncation errors of successive chunks cancel.
+      // between: the result is unchanged and the truncation errors of successive chunks cancel.  (The same multiply
+      // moves the accumulators to the next chunk's scale when that chunk is larger than everything before it.)
+      const float flip = -ldexpf(1.f, s_next - s_run);
 #pragma unroll
       for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) acc[i][j][r] = -acc[i][j][r];
-#pragma unroll
-      for (int r = 0; r < HNR; r++) {
-        *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
-        *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
-      }
+          for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+      s_run = s_next;
+      write_halo();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
 
   // ------------------------------------------------------------------ epilogue (direct 32 x 32 layout)
+  // (sign: the accumulators changed sign nchunks - 1 times)
+  const float out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kScaleNone ? 0 : s_run) + sw));
   const int ox = x0 + (lane & 31);
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
@@ -426,18 +456,21 @@ struct HPackParams {
 };
 
 __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
-  const float w_mult = ldexpf(1.f, scale_exp(*p.absmax_w));
+  const int sw = scale_exp(*p.absmax_w);
+  const float w_mult = ldexpf(1.f, sw == kScaleNone ? 0 : sw);
   const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;   // items of 8 channels
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // the tap runs fastest over the threads: the 27 taps of one (row, channel) are contiguous in the weight tensor, so a
+    // wave's reads are 108-byte runs (with the row fastest every lane read its own 108-byte segment: 4.5 ms per step)
     long long r = e;
+    const int tap = r % 27;
+    r /= 27;
     const int row = r % 32;
     r /= 32;
     const int h = r % 2;
     r /= 2;
     const int rt = r % p.RT;
     r /= p.RT;
-    const int tap = r % 27;
-    r /= 27;
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
     const int n = p.n_off + nb * (32 * p.RT) + rt * 32 + row;
@@ -480,25 +513,6 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     *reinterpret_cast<h8*>(p.img + piece1 * 512 + (h * 32 + row) * 8) = lo;
   }
 }
-
-constexpr int kSlots = 256;
-unsigned* absmax_slots() {   // device scratch, one slot per call (calls on a stream are ordered anyway)
-  static unsigned* slots = nullptr;
-  static std::atomic<int> ready{0};
-  static std::atomic_flag busy = ATOMIC_FLAG_INIT;
-  if (!ready.load(std::memory_order_acquire)) {
-    while (busy.test_and_set(std::memory_order_acquire)) {
-    }
-    if (!ready.load(std::memory_order_relaxed)) {
-      void* ptr = nullptr;
-      if (hipMalloc(&ptr, kSlots * sizeof(unsigned)) == hipSuccess) slots = (unsigned*)ptr;
-      ready.store(1, std::memory_order_release);
-    }
-    busy.clear(std::memory_order_release);
-  }
-  return slots;
-}
-std::atomic<unsigned> g_slot_counter{0};
 
 int absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st) {
   long long blocks = (n / 4 + 255) / 256;
@@ -565,21 +579,6 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
 int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st) {
   SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "split-f16 conv: more than 2^29 voxels per channel");
   SR3D_CHECK(B <= 65535, SR3D_E_ARG, "split-f16 conv: batch too large");
-  unsigned* slots = absmax_slots();
-  SR3D_CHECK(slots != nullptr, SR3D_E_HIP, "split-f16 conv: no device scratch");
-  unsigned* slot = slots + (g_slot_counter.fetch_add(1) % kSlots);
-  {
-    SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
-    SR3D_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
-    double bytes = 0;
-    for (int i = 0; i < p.in.n; i++) {
-      const long long n = (long long)B * p.in.bstride[i];
-      if (int rc = absmax_launch(p.in.ptr[i], n, slot, st)) return rc;
-      bytes += 4.0 * n;
-    }
-    (void)bytes;
-  }
-  p.absmax_x = (const float*)slot;
   p.absmax_w = (const float*)image;
   p.wimg = (const unsigned char*)image + 64;
   p.ntz = ceil_div(p.Z, 2), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);

@@ -39,7 +39,7 @@ def main():
             x64, w64 = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
             y64 = F.conv3d(x64, w64, None, padding=1)
             y64.backward(gy.double().cpu())
-            for mode in ("0", "1"):
+            for mode in ("0", "2"):
                 os.environ["SR3D_SPLIT_F16"] = mode
                 x.grad = None
                 w.grad = None
@@ -70,7 +70,7 @@ def main():
             fn = lambda: ops.conv3d_act(srcs, wf, bias, act="lrelu", stride=1)  # noqa: E731
             ref = F.leaky_relu(F.conv3d(x64, wf.detach().double().cpu(), bias.detach().double().cpu(), padding=1), 0.01)
         outs = {}
-        for mode in ("0", "1"):
+        for mode in ("0", "2"):
             for s in srcs:
                 s.grad = None
             wf.grad = None
@@ -82,7 +82,7 @@ def main():
             torch.cuda.synchronize()
             outs[mode] = (y.detach().clone(), [s.grad.clone() for s in srcs if s.grad is not None], wf.grad.clone())
         y0, g0, w0 = outs["0"]
-        y1, g1, w1 = outs["1"]
+        y1, g1, w1 = outs["2"]
         msg = f"{kind} cs={cs} cout={cout} grid={Z}x{Y}x{X} sc={sc:g}: fwd split-vs-wino {rel(y1, y0):.2e}"
         msg += "  dgrad " + " ".join(f"{rel(a, b):.2e}" for a, b in zip(g1, g0)) + f"  wgrad {rel(w1, w0):.1e}"
         if ref is not None:
