@@ -103,6 +103,36 @@ size_t sr3d_hconv_image_bytes(int rows, int K);
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
                     const int* cbeg, void* image, hipStream_t st);
 int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st);
+// split-f16 stride-2 conv over parity classes (sr3d_hconv_s2.hip): mode 1 = forward, mode 2 = input gradient
+struct SrHconvS2Params {
+  ChanCat in;          // K side (virtual concat): x (mode 1) or dy (mode 2)
+  int K;
+  int IZ, IY, IX;      // grid of the K-side tensors
+  int Z, Y, X;         // mode 1: output grid; mode 2: grid of dx (the per-class tile spaces are cZ/cY/cX)
+  int ntz, nty, ntx, nblk, nchunks;   // set by sr3d_hconv_s2_launch
+  int nb_off;
+  const void* wimg;
+  const float* absmax_w;
+  int N;
+  int n_off;
+  int epi, act;
+  const float* bias;
+  const float* bias2;
+  ChanCat out;
+  float* y;
+  float* save_f;
+  float* save_s;
+  int TZ_, TY_, TX_;   // destination tensor grid
+  int Cg;
+  long long blk_stride;    // mode 1: bytes of one row block of the image
+  long long cls_off[8];    // mode 2: byte offset of the class image, bytes of one of its row blocks
+  long long cls_blk[8];
+  int cZ[8], cY[8], cX[8];
+};
+size_t sr3d_hconv_s2_image_bytes(int rows, int K);
+int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
+                       const int* rbeg, const int* cbeg, void* image, hipStream_t st);
+int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, hipStream_t st);
 // Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
 // (the first `c_used` input channels; dW rows keep their full length d->Cin * 27)
 size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);

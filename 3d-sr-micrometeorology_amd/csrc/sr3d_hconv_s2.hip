@@ -1,0 +1,593 @@
+// Stride-2 3x3x3 convolution on the split-f16 scheme of sr3d_hconv.hip (fp32 operands as two fp16 halves, three
+// v_mfma_f32_32x32x16_f16 per product group, fp32 accumulate, block-floating-point scaling, sign-alternating
+// accumulation): the forward conv of the DownBlocks and its input gradient.
+//
+// A stride-2 conv reads every input voxel for 27/8 outputs on average, so a direct halo tile is 8x larger per output
+// than at stride 1 (5 x 9 x 65 voxels for 2 x 4 x 32 outputs: 187 KB as split fp16).  Both directions are therefore
+// written as stride-1 convolutions over PARITY CLASSES with 1, 2, 4 or 8 taps (27 in total):
+//   forward   y[o] = sum_k w[k] x[2o + k - 1]:  x splits into 8 sub-volumes x_p[q] = x[2q + p]; per dimension an even
+//             class contributes the tap k = 1 at q = o, an odd class the taps k = 0 at q = o - 1 and k = 2 at q = o.
+//             MODE 1: the chunk loop runs over (class, 16 channels); a chunk has (1+pz)(1+py) phases of (1+px) taps.
+//   gradient  dx[2i + q] = sum over the taps that reach parity q: even: k = 1 from dy[i]; odd: k = 0 from dy[i + 1]
+//             and k = 2 from dy[i].  MODE 2: one launch, blockIdx.z = output class; chunks run over 16 dy channels.
+// The halo of a 2 x 4 x 32 tile is then 3 x 5 x 33 voxels per class in the stride-1 kernel's LDS layout (same
+// pitches), 40 % of which the range-checked buffer loads skip without traffic.
+//
+// Per chunk only 12 .. 96 MFMAs per wave stand against the staging of 16 x 495 values, so the pipeline is simpler
+// than at stride 1: the halo refill is not overlapped inside a workgroup; the second workgroup of the CU covers it.
+#include "sr3d_common.h"
+
+#include <limits.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_p;
+
+constexpr int HKC = 16;
+constexpr int HHY = 6, HHX = 34;               // LDS pitches of sr3d_hconv.hip; used region 3 x 5 x 33
+constexpr int UZ = 3, UY = 5, UX = 33;
+constexpr int HNR = 5;                         // staging rounds: voxel indices < 3 * 6 * 34 = 612 <= 10 * 64
+constexpr int HVOX = 816, HVP = 896;           // plane geometry of sr3d_hconv.hip (kept: same bank behaviour)
+constexpr int HPLANE = HVP * 16;
+constexpr int HBYTES = 4 * HPLANE;
+constexpr int HNT = 256;
+template <int RT>
+struct SGeo {
+  static constexpr int WBUF = 2 * 2 * RT * 1024;   // one phase: up to 2 taps x 2 parts x RT fragments
+  static constexpr size_t LDS = HBYTES + 2 * (size_t)WBUF;
+};
+static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_p dst, int voffset) {
+#if __HIP_DEVICE_COMPILE__   // (see sr3d_hconv.hip: the host pass rejects the 16-byte size)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void pin_scalar(T& x) {
+  asm volatile("" : "+s"(x));
+}
+constexpr int kScaleNone = 120;
+__device__ __forceinline__ int scale_exp(float amax) {
+  if (amax != amax || amax > 3.0e38f) return 0;
+  if (!(amax > 0.f)) return kScaleNone;
+  int e;
+  frexpf(amax, &e);
+  const int s = 14 - e;
+  return s > kScaleNone ? kScaleNone : s;
+}
+__device__ __forceinline__ float hact(float v, int act) {
+  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+// halo coordinate of local tap i in a dimension of parity `par` (host and device)
+//   MODE 1 (forward):  even: k = 1 at h = 1;  odd: i = 0 -> k = 0 at h = 0, i = 1 -> k = 2 at h = 1   (halo origin o0 - 1)
+//   MODE 2 (gradient): even: k = 1 at h = 0;  odd: i = 0 -> k = 0 at h = 1, i = 1 -> k = 2 at h = 0   (halo origin i0)
+__host__ __device__ inline int tap_h(int mode, int par, int i) { return mode == 1 ? (par ? i : 1) : (par ? 1 - i : 0); }
+__host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
+
+template <int RT, int MODE>
+__global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params p) {
+  using G = SGeo<RT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Hs = lds;
+  unsigned char* Ws = lds + HBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < HNT / 64);
+
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = v % p.nblk;
+  int blk = v / p.nblk;
+  const int tix = blk % p.ntx;
+  blk /= p.ntx;
+  const int tiy = blk % p.nty;
+  const int tiz = blk / p.nty;
+  const int b = blockIdx.y;
+  const int ocls = MODE == 2 ? (int)blockIdx.z : 0;                 // output parity class of this launch slice
+  const int TZ = MODE == 2 ? p.cZ[ocls] : p.Z, TY = MODE == 2 ? p.cY[ocls] : p.Y, TX = MODE == 2 ? p.cX[ocls] : p.X;
+  const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
+  if (z0 >= TZ || y0 >= TY || x0 >= TX) return;                     // (the grid is sized for the largest class)
+  const long long IZYX = (long long)p.IZ * p.IY * p.IX;
+  const int chan_bytes = (int)(IZYX * 4);
+
+  int sw = scale_exp(*p.absmax_w);
+  if (sw == kScaleNone) sw = 0;
+  float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
+
+  // ---- staging geometry (class-independent part): halo voxel of this lane in round r
+  const int sh = wave & 1;
+  int hq[HNR];          // packed (hz, hy, hx) or -1
+  int swr[HNR];
+#pragma unroll
+  for (int r = 0; r < HNR; r++) {
+    const int e = (r * 2 + (wave >> 1)) * 64 + lane;
+    const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
+    const int hy = r2 / HHX, hx = r2 - hy * HHX;
+    hq[r] = (hz < UZ && hy < UY && hx < UX) ? (hz << 16 | hy << 8 | hx) : -1;
+    swr[r] = e * 16;
+  }
+  // byte offset of that voxel inside a channel volume for K-side class (cz, cy, cx); 0xffffffff = zero
+  auto src_off = [&](const int r, const int cz, const int cy, const int cx) -> unsigned {
+    if (hq[r] < 0) return 0xffffffffu;
+    const int hz = hq[r] >> 16, hy = (hq[r] >> 8) & 255, hx = hq[r] & 255;
+    int gz, gy, gx;
+    if (MODE == 1) {   // sub-volume index q = o0 - 1 + h, input coordinate 2q + class parity
+      gz = 2 * (z0 - 1 + hz) + cz, gy = 2 * (y0 - 1 + hy) + cy, gx = 2 * (x0 - 1 + hx) + cx;
+    } else {           // dy coordinate i0 + h
+      gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;
+    }
+    const bool ok = (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;
+    return ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * 4u : 0xffffffffu;
+  };
+
+  // per-slice base pointers in scalar registers, mask arithmetic (see sr3d_hconv.hip)
+#define SR3D_SLICE_BASE(i) reinterpret_cast<unsigned long long>(p.in.ptr[i] + (long long)b * p.in.bstride[i])
+  unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
+#undef SR3D_SLICE_BASE
+  int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
+  pin_scalar(sb0), pin_scalar(sb1), pin_scalar(sb2), pin_scalar(sb3);
+  pin_scalar(cb0), pin_scalar(cb1), pin_scalar(cb2), pin_scalar(cb3);
+  unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
+  int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
+  pin_scalar(dsb1), pin_scalar(dsb2), pin_scalar(dsb3), pin_scalar(dcb1), pin_scalar(dcb2), pin_scalar(dcb3);
+  auto chan_base = [&](const int gc) {
+    const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
+    const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
+    const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
+    return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
+  };
+
+  // ---- chunk iteration space.  MODE 1: virtual chunk vc = class * cpc + cc (class = K-side parity).  MODE 2: vc = cc,
+  // the tap structure comes from the launch's output class.
+  const int cpc = p.nchunks;
+  const int NV = MODE == 1 ? 8 * cpc : cpc;
+  auto cls_of = [&](const int vc) { return MODE == 1 ? vc / cpc : ocls; };
+
+  float raw[HNR][8];
+  auto load_raw = [&](const int vc) {
+    const int kc = MODE == 1 ? vc / cpc : 0;                       // K-side class (mode 2: dy is not subsampled)
+    const int cc = MODE == 1 ? vc - kc * cpc : vc;
+    const bool live = vc < NV;
+    const int gc0 = cc * HKC + sh * 8;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gc = gc0 + c;
+      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < HNR; r++)
+        raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, src_off(r, (kc >> 2) & 1, (kc >> 1) & 1, kc & 1), 0, 0));
+    }
+  };
+  auto publish_max = [&](const int parity) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < HNR; r++)
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) xmax[parity * 4 + wave] = m;
+  };
+  auto next_scale = [&](const int parity, const int s_run) {
+    const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
+    const int s_c = __builtin_amdgcn_readfirstlane(scale_exp(m));
+    return s_c < s_run ? s_c : s_run;
+  };
+  auto split_and_write = [&](const float in_mult) {
+#pragma unroll
+    for (int r = 0; r < HNR; r++) {
+      h8 hi, lo;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float sc = raw[r][c] * in_mult;
+        const _Float16 a = (_Float16)sc;
+        hi[c] = a;
+        lo[c] = (_Float16)(sc - (float)a);
+      }
+      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;   // (rounds 0..4 stay below voxel 640: no slot there)
+      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
+    }
+  };
+
+  // ---- weights: the phases of this workgroup's row block are contiguous in execution order
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wimg) + (MODE == 2 ? p.cls_off[ocls] : 0) +
+                               (size_t)(p.nb_off + nblk) * (MODE == 2 ? p.cls_blk[ocls] : p.blk_stride);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)(MODE == 2 ? p.cls_blk[ocls] : p.blk_stride), 0x00020000);
+  auto dma_w = [&](const int woff, const int npieces, unsigned char* W) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++) {
+      const int i = wave + 4 * ii;
+      if (i < npieces) lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
+    }
+  };
+
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int vt = 2 * wave + j;
+    bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
+  }
+  const int abase = lane * 16;
+
+  // ---- prologue: weights of the first phase, first chunk staged
+  int cls = cls_of(0);
+  int nxp = 1 + (cls & 1);                      // taps of a phase in this chunk's class
+  int woff = 0, gph = 0;
+  dma_w(0, nxp * 2 * RT, Ws);
+  load_raw(0);
+  publish_max(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int s_run = next_scale(0, kScaleNone);
+  split_and_write(ldexpf(1.f, s_run));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int vc = 0; vc < NV; vc++) {
+    cls = cls_of(vc);
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int ny = 1 + py, nph = (1 + pz) * ny;
+    nxp = 1 + px;
+    const int cls_n = vc + 1 < NV ? cls_of(vc + 1) : cls;
+    for (int ph = 0; ph < nph; ph++, gph++) {
+      const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
+      const int wsize = nxp * 2 * RT * 1024;
+      const bool last = ph + 1 == nph;
+      if (!(last && vc + 1 == NV)) dma_w(woff + wsize, (last ? 1 + (cls_n & 1) : nxp) * 2 * RT, Ws + ((gph + 1) & 1) * G::WBUF);
+      __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
+      if (ph == 0) load_raw(vc + 1);
+      const int iz = ph / ny, iy = ph - iz * ny;
+      const unsigned char* Hk = Hs + ((tap_h(MODE, pz, iz) * HHY + tap_h(MODE, py, iy)) * HHX) * 16;
+      h8 fa[2][2][RT], fb[2][2][2];   // [tap][part][row tile], [tap][part][voxel row]
+#pragma unroll
+      for (int ix = 0; ix < 2; ix++) {
+        if (ix < nxp) {
+          const int hx = tap_h(MODE, px, ix);
+#pragma unroll
+          for (int part = 0; part < 2; part++) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) fa[ix][part][i] = *reinterpret_cast<const h8*>(W + ((ix * 2 + part) * RT + i) * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[ix][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + hx * 16);
+          }
+        }
+      }
+#pragma unroll
+      for (int ix = 0; ix < 2; ix++) {
+        if (ix < nxp) {
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][1][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][1][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      // next phase's weights landed (older than the 8 * HNR raw-row loads issued in phase 0)
+      if (ph == 0)
+        asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      woff += wsize;
+    }
+    if (vc + 1 < NV) {
+      publish_max((vc + 1) & 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int s_next = next_scale((vc + 1) & 1, s_run);
+      const float flip = -ldexpf(1.f, s_next - s_run);   // sign alternation + rescale, see sr3d_hconv.hip
+#pragma unroll
+      for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+      s_run = s_next;
+      split_and_write(ldexpf(1.f, s_run));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const float out_mult = ldexpf((NV & 1) ? 1.f : -1.f, -((s_run == kScaleNone ? 0 : s_run) + sw));
+  const int ox = x0 + (lane & 31);
+  const int rblock = p.n_off + (p.nb_off + nblk) * 64;
+  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
+  if (ox >= TX) return;
+  if (MODE == 1 && p.epi == SR3D_EPI_GATED) {
+    if constexpr (RT == 2) {
+      const int cbase = rblock / 2 + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int vt = 2 * wave + j;
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+        if (oz >= TZ || oy >= TY) continue;
+        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2);
+          if (co < p.Cg) {
+            float f = acc[0][j][r] * out_mult;
+            if (p.bias) f += p.bias[co];
+            const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
+            const float s = 1.f / (1.f + expf(-g));
+            f = hact(f, p.act);
+            const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+            p.y[o] = s * f;
+            if (p.save_f) {
+              p.save_f[o] = f;
+              p.save_s[o] = s;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const int so = MODE == 2 ? 2 : 1;
+    const int qz = MODE == 2 ? (ocls >> 2) & 1 : 0, qy = MODE == 2 ? (ocls >> 1) & 1 : 0, qx = MODE == 2 ? ocls & 1 : 0;
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        if (n >= p.N) continue;
+        const int si = cat_find(p.out, n);
+        float* base = cat_ptr(p.out, si);
+        if (base == nullptr) continue;
+        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int vt = 2 * wave + j;
+          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+          if (oz < TZ && oy < TY)
+            base[((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx)] = hact(acc[i][j][r] * out_mult + bv, p.act);
+        }
+      }
+  }
+}
+
+// ---- weight split + packing.  Image of one row block (MODE 1) / of one (class, row block) (MODE 2), in execution
+// order: [class][chunk][phase (iz, iy)][ix][part][row tile][channel half][32 rows][8 ch] fp16
+struct S2PackParams {
+  const float* w1;
+  const float* w2;
+  const float* absmax_w;
+  _Float16* img;
+  int Cout, Cin, kind, K, N, cpc, nblk, RT, n_off, mode;
+  int rbeg[SR3D_MAX_SRC + 1];
+  int cbeg[SR3D_MAX_SRC];
+};
+
+__host__ __device__ inline int cls_taps(int cls) { return (1 + ((cls >> 2) & 1)) * (1 + ((cls >> 1) & 1)) * (1 + (cls & 1)); }
+// taps of the classes before `cls` (classes in order 0..7)
+__host__ __device__ inline int cls_taps_before(int cls) {
+  int s = 0;
+  for (int c = 0; c < cls; c++) s += cls_taps(c);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p) {
+  const int sw = scale_exp(*p.absmax_w);
+  const float w_mult = ldexpf(1.f, sw == kScaleNone ? 0 : sw);
+  // items: (row block, class, chunk, local tap, row tile, channel half, row); 27 taps over the 8 classes
+  const long long total = (long long)p.nblk * p.cpc * 27 * p.RT * 64;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    long long r = e;
+    const int tg = r % 27;     // global tap slot: class by cumulative tap count
+    r /= 27;
+    const int row = r % 32;
+    r /= 32;
+    const int h = r % 2;
+    r /= 2;
+    const int rt = r % p.RT;
+    r /= p.RT;
+    const int cc = r % p.cpc;
+    const int nb = r / p.cpc;
+    int cls = 0;
+    while (cls < 7 && tg >= cls_taps_before(cls + 1)) cls++;
+    const int tl = tg - cls_taps_before(cls);                       // local tap = (iz * ny + iy) * nx + ix
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int nx = 1 + px, ny = 1 + py;
+    const int ix = tl % nx, iy = (tl / nx) % ny, iz = tl / (nx * ny);
+    const int tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + tap_k(px, ix);   // original (kz, ky, kx)
+    const int n = p.n_off + nb * (32 * p.RT) + rt * 32 + row;
+    // execution-order chunk index (sign alternation): MODE 1: class * cpc + cc; MODE 2: cc (one class per image)
+    const int vc = p.mode == 1 ? cls * p.cpc + cc : cc;
+    const float* w = nullptr;
+    long long kstride = 27;
+    if (p.kind == SR3D_PACK_FWD) {
+      if (n < p.N) w = p.w1 + (long long)n * p.Cin * 27;
+    } else if (p.kind == SR3D_PACK_FWD_GATED) {
+      const int co = (n >> 6) * 32 + (n & 31);
+      if (co < p.Cout) w = ((n & 32) ? p.w2 : p.w1) + (long long)co * p.Cin * 27;
+    } else if (n < p.N) {
+      const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
+      const int ci = p.cbeg[si] + (n - p.rbeg[si]);
+      w = p.w1 + (long long)ci * 27;
+      kstride = (long long)p.Cin * 27;
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = cc * HKC + h * 8 + j;
+      float val = 0.f;
+      if (w != nullptr && k < p.K) {
+        if (p.kind == SR3D_PACK_BWD || p.kind == SR3D_PACK_BWD_GATED) {
+          const float* src = k < p.Cout ? w + (long long)k * kstride : (p.w2 + (w - p.w1)) + (long long)(k - p.Cout) * kstride;
+          val = src[tap];
+        } else {
+          val = w[(long long)k * kstride + tap];
+        }
+      }
+      const float s = val * ((vc & 1) ? -w_mult : w_mult);
+      const _Float16 a = (_Float16)s;
+      hi[j] = a;
+      lo[j] = (_Float16)(s - (float)a);
+    }
+    // piece index inside the image
+    long long piece;
+    if (p.mode == 1) {   // row block: classes one after the other, each [cc][local tap][part][rt]
+      piece = (long long)nb * p.cpc * 27 + (long long)cls_taps_before(cls) * p.cpc + (long long)cc * cls_taps(cls) + tl;
+    } else {             // the 8 class images one after the other, each [row block][cc][local tap]
+      piece = (long long)cls_taps_before(cls) * p.cpc * p.nblk + ((long long)nb * p.cpc + cc) * cls_taps(cls) + tl;
+    }
+    _Float16* dst = p.img + (piece * 2 * p.RT) * 512 + (h * 32 + row) * 8;
+    *reinterpret_cast<h8*>(dst + (0 * p.RT + rt) * 512) = hi;
+    *reinterpret_cast<h8*>(dst + (1 * p.RT + rt) * 512) = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_w_kernel(const float* __restrict__ x, long long n, unsigned* slot) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
+inline void row_split(int rows, int* n2, int* n1) {
+  const int nfull = rows / 64, rem = rows - nfull * 64;
+  *n2 = nfull + (rem > 32 ? 1 : 0);
+  *n1 = (rem > 0 && rem <= 32) ? 1 : 0;
+}
+
+template <int MODE>
+void launch_rt(int rt, dim3 grid, hipStream_t st, const SrHconvS2Params& p) {
+  if (rt == 2)
+    hipLaunchKernelGGL((hconv_s2_kernel<2, MODE>), grid, dim3(HNT), SGeo<2>::LDS, st, p);
+  else
+    hipLaunchKernelGGL((hconv_s2_kernel<1, MODE>), grid, dim3(HNT), SGeo<1>::LDS, st, p);
+}
+
+}  // namespace
+
+// header (64 bytes) + region A (64-row blocks) + region B (one block of <= 32 rows); 27 taps per (row block, chunk)
+size_t sr3d_hconv_s2_image_bytes(int rows, int K) {
+  int n2, n1;
+  row_split(rows, &n2, &n1);
+  return 64 + (size_t)ceil_div(K, HKC) * 27 * 2 * 1024 * ((size_t)n2 * 2 + (size_t)n1);
+}
+
+int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
+                       const int* rbeg, const int* cbeg, void* image, hipStream_t st) {
+  unsigned* hdr = (unsigned*)image;
+  SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
+  const long long nw = (long long)Cout * Cin * 27;
+  const int ab = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
+  hipLaunchKernelGGL(absmax_w_kernel, dim3(ab), dim3(256), 0, st, w1, nw, hdr);
+  if (w2 != nullptr) hipLaunchKernelGGL(absmax_w_kernel, dim3(ab), dim3(256), 0, st, w2, nw, hdr);
+  SR3D_HIP(hipGetLastError());
+  S2PackParams p{};
+  p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
+  p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.cpc = ceil_div(K, HKC), p.mode = mode;
+  for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
+  for (int i = 0; i < SR3D_MAX_SRC; i++) p.cbeg[i] = cbeg ? cbeg[i] : 0;
+  int n2, n1;
+  row_split(rows, &n2, &n1);
+  _Float16* body = (_Float16*)((unsigned char*)image + 64);
+  for (int region = 0; region < 2; region++) {
+    p.nblk = region == 0 ? n2 : n1;
+    if (p.nblk == 0) continue;
+    p.RT = region == 0 ? 2 : 1;
+    p.n_off = region == 0 ? 0 : n2 * 64;
+    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.cpc * 27 * 2 * 2 * 512);
+    const long long total = (long long)p.nblk * p.cpc * 27 * p.RT * 64;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(hconv_s2_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
+    SR3D_HIP(hipGetLastError());
+  }
+  return SR3D_OK;
+}
+
+// p: in, K, IZ/IY/IX, Z/Y/X (mode 1: output grid; mode 2: fine grid of dx), N, n_off, epilogue fields, TZ_/TY_/TX_
+int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, hipStream_t st) {
+  SR3D_CHECK((long long)p.IZ * p.IY * p.IX < (1ll << 29), SR3D_E_ARG, "split-f16 conv: more than 2^29 voxels per channel");
+  SR3D_CHECK(B <= 65535, SR3D_E_ARG, "split-f16 conv: batch too large");
+  p.absmax_w = (const float*)image;
+  p.nchunks = ceil_div(p.K, HKC);
+  int n2, n1;
+  row_split(p.N, &n2, &n1);
+  static thread_local bool configured = false;
+  if (!configured) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
+    configured = true;
+  }
+  int gz, gy, gx;   // tile space of the launch (mode 2: class 0 = even positions, the largest)
+  if (mode == 1) {
+    gz = p.Z, gy = p.Y, gx = p.X;
+  } else {
+    for (int c = 0; c < 8; c++)
+      p.cZ[c] = (p.Z - ((c >> 2) & 1) + 1) / 2, p.cY[c] = (p.Y - ((c >> 1) & 1) + 1) / 2, p.cX[c] = (p.X - (c & 1) + 1) / 2;
+    gz = p.cZ[0], gy = p.cY[0], gx = p.cX[0];
+  }
+  p.ntz = ceil_div(gz, 2), p.nty = ceil_div(gy, 4), p.ntx = ceil_div(gx, 32);
+  const long long nsp = (long long)p.ntz * p.nty * p.ntx;
+  SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
+  void* tok = nullptr;
+  if (sr3d_prof_active()) {
+    const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
+    double vox = 0;
+    if (mode == 1) {
+      vox = 27.0 * p.Z * p.Y * p.X;
+    } else {
+      for (int c = 0; c < 8; c++) vox += (double)cls_taps(c) * p.cZ[c] * p.cY[c] * p.cX[c];
+    }
+    sr3d_prof_begin(mode == 1 ? SR3D_PROF_IGEMM_S2 : SR3D_PROF_IGEMM_BWD_S2, 2.0 * p.K * rows * vox * B, st, &tok);
+  }
+  const unsigned char* body = (const unsigned char*)image + 64;
+  const size_t cpc = p.nchunks;
+  for (int region = 0; region < 2; region++) {
+    const int nb = region == 0 ? n2 : n1, rt = region == 0 ? 2 : 1;
+    if (nb == 0) continue;
+    SrHconvS2Params q = p;
+    q.nblk = nb, q.nb_off = 0;
+    q.n_off = p.n_off + (region == 0 ? 0 : n2 * 64);
+    q.wimg = body + (region == 0 ? 0 : (size_t)n2 * cpc * 27 * 2 * 2 * 1024);
+    const size_t piece = (size_t)2 * rt * 1024;   // bytes of one tap (2 parts x rt fragments)
+    if (mode == 1) {
+      q.blk_stride = (long long)(cpc * 27 * piece);
+    } else {
+      for (int c = 0; c < 8; c++) {
+        q.cls_off[c] = (long long)((size_t)cls_taps_before(c) * cpc * nb * piece);
+        q.cls_blk[c] = (long long)(cpc * cls_taps(c) * piece);
+      }
+    }
+    const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
+    if (mode == 1)
+      launch_rt<1>(rt, grid, st, q);
+    else
+      launch_rt<2>(rt, grid, st, q);
+  }
+  sr3d_prof_end(tok, st);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}

@@ -452,6 +452,14 @@ inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
   const long long wgs = (long long)d->B * ceil_div(d->Z, 2) * ceil_div(d->Y, 4) * ceil_div(d->X, 32) * ceil_div(rows, 64);
   return wgs >= 448;
 }
+// ... and the stride-2 layers on its parity-class form (sr3d_hconv_s2.hip); bwd: 8 class launches over the coarse grid
+inline bool use_hconv_s2(const sr3d_conv_desc_t* d, int K, int rows) {
+  const int mode = sr3d_hconv_mode();
+  if (d->stride != 2 || K < 32 || rows < 16 || mode == 0) return false;
+  if (mode == 2) return true;
+  const int oz = (d->Z - 1) / 2 + 1, oy = (d->Y - 1) / 2 + 1, ox = (d->X - 1) / 2 + 1;
+  return (long long)d->B * ceil_div(oz, 2) * ceil_div(oy, 4) * ceil_div(ox, 32) * ceil_div(rows, 64) >= 448;
+}
 inline int hconv_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 64 * ((d->Cout + 31) / 32) : d->Cout;
 }
@@ -690,6 +698,16 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
   p.OZ = out_dim(d->Z, d->stride), p.OY = out_dim(d->Y, d->stride), p.OX = out_dim(d->X, d->stride);
   p.TZ_ = p.OZ * dst_scale, p.TY_ = p.OY * dst_scale, p.TX_ = p.OX * dst_scale;
   p.s_out = 1, p.pz = p.py = p.px = 0;
+  if (use_hconv_s2(d, d->Cin, p.N) && p.epi != EPI_UNSHUFFLE) {
+    SrHconvS2Params q{};
+    q.in = p.in, q.K = p.K;
+    q.IZ = d->Z, q.IY = d->Y, q.IX = d->X;
+    q.Z = p.OZ, q.Y = p.OY, q.X = p.OX;
+    q.N = p.N, q.n_off = 0, q.epi = p.epi, q.act = p.act, q.bias = p.bias, q.bias2 = p.bias2;
+    q.out = p.out, q.y = p.y, q.save_f = p.save_f, q.save_s = p.save_s, q.Cg = p.Cg;
+    q.TZ_ = p.TZ_, q.TY_ = p.TY_, q.TX_ = p.TX_;
+    return sr3d_hconv_s2_launch(1, q, image, d->B, st);
+  }
   p.nchunks = ceil_div(p.K, kKC);
   const RowPlan rp = fwd_plan(d, p.N, p.epi == EPI_GATED);
   if (d->stride == 1) {
@@ -710,6 +728,7 @@ size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_image_bytes(hconv_fwd_rows(d, kind), d->Cin);
+  if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_s2_image_bytes(hconv_fwd_rows(d, kind), d->Cin);
   if (use_wino(d)) return sr3d_wino_image_floats(wino_fwd_rows(d, kind), d->Cin) * 4;
   return image_floats(ceil_div(fwd_rows(d, kind), 32), ceil_div(d->Cin, kKC), 27) * 4;
 }
@@ -729,6 +748,9 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)))
     return sr3d_hconv_pack(kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                            (const float*)w_gate, nullptr, nullptr, w_packed, (hipStream_t)stream);
+  if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind)))
+    return sr3d_hconv_s2_pack(1, kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
+                              (const float*)w_gate, nullptr, nullptr, w_packed, (hipStream_t)stream);
   if (use_wino(d))
     return sr3d_wino_pack(kind, d->Cout, d->Cin, wino_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                           (const float*)w_gate, nullptr, nullptr, (float*)w_packed, (hipStream_t)stream);
@@ -875,8 +897,10 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   const size_t hc = use_hconv(d, n_dy * d->Cout, d->Cin)
                         ? ((sr3d_hconv_image_bytes(d->Cin, n_dy * d->Cout) + 255) & ~(size_t)255) + (size_t)n_dy * d->Cout * 108 * 4
                         : 0;
-  const size_t m = direct > wino ? direct : wino;
-  return m > hc ? m : hc;
+  const size_t hs2 = use_hconv_s2(d, n_dy * d->Cout, d->Cin) ? sr3d_hconv_s2_image_bytes(d->Cin, n_dy * d->Cout) : 0;
+  size_t m = direct > wino ? direct : wino;
+  m = m > hc ? m : hc;
+  return m > hs2 ? m : hs2;
 }
 
 int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
@@ -982,6 +1006,16 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     using C = IgemmCfg<1, -1, 1, 2, 4, 4, kKC>;
     full_taps(p, C::HY, C::HX, true);
     return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
+  }
+  if (use_hconv_s2(d, K, rows)) {
+    SrHconvS2Params q{};
+    q.in = p.in, q.out = p.out, q.K = K, q.N = rows, q.n_off = 0;
+    q.IZ = OZ, q.IY = OY, q.IX = OX;
+    q.Z = d->Z, q.Y = d->Y, q.X = d->X;
+    q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
+    if (int rc = sr3d_hconv_s2_pack(2, pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
+    return sr3d_hconv_s2_launch(2, q, image, d->B, st);
   }
   using C = IgemmCfg<1, 0, 1, 2, 4, 4, kKC>;
   // the 8 output-parity classes: packed one after the other, then ONE launch with blockIdx.z = class

@@ -27,7 +27,7 @@ def forced(monkeypatch):
     monkeypatch.setenv("SR3D_SPLIT_F16", "2")
 
 
-def _ref_and_inputs(cs, cout, grid, kind, scale, seed, batch=2):
+def _ref_and_inputs(cs, cout, grid, kind, scale, seed, batch=2, stride=1):
     g = torch.Generator().manual_seed(seed)
     Z, Y, X = grid
     xs = [((torch.rand(batch, c, Z, Y, X, generator=g) - 0.3) * scale).double().requires_grad_(c > 1) for c in cs]
@@ -37,10 +37,10 @@ def _ref_and_inputs(cs, cout, grid, kind, scale, seed, batch=2):
     bias = (torch.randn(cout, generator=g) * 0.1 * scale).double().requires_grad_(True)
     x = torch.cat(xs, 1)
     if kind == "gated":
-        pre_f, pre_g = F.conv3d(x, wf, None, padding=1), F.conv3d(x, wg, bias, padding=1)
+        pre_f, pre_g = F.conv3d(x, wf, None, stride=stride, padding=1), F.conv3d(x, wg, bias, stride=stride, padding=1)
         ref = torch.sigmoid(pre_g) * torch.relu(pre_f)
     else:
-        pre_f = F.conv3d(x, wf, bias, padding=1)
+        pre_f = F.conv3d(x, wf, bias, stride=stride, padding=1)
         ref = F.leaky_relu(pre_f, 0.01)
     gy = (torch.rand(ref.shape, generator=g) - 0.5).double()
     # keep the comparison on the smooth part: no gradient through pre-activations within 1e-4 of the kink
@@ -72,6 +72,37 @@ def test_split_f16_layers_vs_fp64(eng, forced, cs, cout, grid, kind, scale):
         y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act="relu", stride=1)
     else:
         y = eng.ops.conv3d_act(xd, wfd, bd, act="lrelu", stride=1)
+    assert relerr(y, ref) < TOL
+    y.backward(dev(gy))
+    for a, b in zip(xd, xs):
+        if b.requires_grad:
+            assert relerr(a.grad, b.grad) < TOL
+    assert relerr(wfd.grad, wf.grad) < TOL and relerr(bd.grad, bias.grad) < TOL
+    if kind == "gated":
+        assert relerr(wgd.grad, wg.grad) < TOL
+
+
+# stride 2 (csrc/sr3d_hconv_s2.hip: parity classes): odd and even grids, a concat boundary inside a chunk, row blocks of
+# 32 / 40 / 64 / 130 rows, the mask-like single channel that needs no gradient
+S2_CASES = [
+    ([64, 1], 64, (8, 16, 64), "gated", 1.0),
+    ([33], 40, (5, 7, 33), "plain", 1.0),
+    ([48], 130, (6, 9, 70), "plain", 50.0),
+    ([40, 1, 24], 32, (7, 8, 34), "gated", 1e-6),
+]
+
+
+@pytest.mark.parametrize("cs,cout,grid,kind,scale", S2_CASES)
+def test_split_f16_stride2_layers_vs_fp64(eng, forced, cs, cout, grid, kind, scale):
+    xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, scale, seed=7 * sum(cs) + cout, stride=2)
+    dev = lambda t: t.detach().float().to(DEV)   # noqa: E731
+    xd = [dev(x).requires_grad_(x.requires_grad) for x in xs]
+    wfd, wgd, bd = dev(wf).requires_grad_(True), dev(wg).requires_grad_(True), dev(bias).requires_grad_(True)
+    if kind == "gated":
+        y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act="relu", stride=2)
+    else:
+        y = eng.ops.conv3d_act(xd, wfd, bd, act="lrelu", stride=2)
+    assert y.shape == ref.shape
     assert relerr(y, ref) < TOL
     y.backward(dev(gy))
     for a, b in zip(xd, xs):
