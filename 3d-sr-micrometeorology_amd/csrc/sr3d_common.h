@@ -133,6 +133,11 @@ size_t sr3d_hconv_s2_image_bytes(int rows, int K);
 int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
                        const int* rbeg, const int* cbeg, void* image, hipStream_t st);
 int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, hipStream_t st);
+// split-f16 weight gradient of the stride-1 layers (sr3d_hwgrad.hip); same contract as sr3d_wino_wgrad
+size_t sr3d_hwgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);
+bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy);
+int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw, float* ws,
+                hipStream_t st);
 // Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
 // (the first `c_used` input channels; dW rows keep their full length d->Cin * 27)
 size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);

@@ -1,0 +1,381 @@
+// Weight gradient of the stride-1 3x3x3 convolutions on the split-f16 scheme of sr3d_hconv.hip (fp32 operands as two
+// fp16 halves, three v_mfma_f32_32x32x16_f16 per product group, fp32 accumulate):
+//
+//   dW[n][c][kz,ky,kx] = sum_{b,z,y,x'} dY[n][z][y][x' - kx + 1] * X[c][z + kz - 1][y + ky - 1][x']
+//
+// One MFMA reduces over K = 16 consecutive x' of one row: A = a dY row segment (rows n), B = an X row segment (columns
+// c).  The tap shifts in z and y pick WHICH X row a wave reads; the shift in x would make one operand start one
+// element off a 16-byte boundary -- so the smaller operand (dY) is staged three times, shifted by -1, 0, +1, and every
+// fragment is one aligned ds_read_b128.
+//
+// Workgroup = 10 waves: an (n-block of 32 * RT rows) x (c-block of 32 channels) x (x segment of 32 voxels) x (a range
+// of (b, z, y) rows, split-K).  Wave w < 9 owns the taps (kz, ky) = (w / 3, w % 3) x 3 kx: 3 * RT accumulator tiles.
+// It marches along y: per step ONE new X row of each of the 3 z planes (4 y slots per plane in LDS) and one dY row
+// (3 shifted copies, double-buffered) are staged, by waves 0-5 (X) and 6-9 (dY), one 8-voxel piece per thread,
+// loaded a step ahead into registers, then scaled, split and written; one barrier per step.
+// Scales: one power of two per tensor from max|x| / max|dY| (separate pass, sr3d_absmax): exact, no overflow.
+// The f16 MFMA's truncation bias (sr3d_hconv.hip) is cancelled by flipping the sign of the dY rows and of the
+// accumulators every 32 rows.  Partial sums per (split, x segment) go to a slab [.][tap][n][c]; a second kernel adds them
+// in a fixed order (deterministic), undoes the scaling and writes dW[n][c][tap].
+#include "sr3d_common.h"
+
+#include <limits.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int WNT = 640;
+constexpr int PITCH = 80;                          // bytes per 32-voxel fp16 row in LDS (64 + 16: conflict-free b128)
+constexpr int XROW = 2 * 32 * PITCH;               // one X row: [part][c 32][PITCH]
+constexpr int XBYTES = 12 * XROW;                  // 3 planes x 4 y slots
+template <int RT>
+struct WGeo {
+  static constexpr int DCOPY = 2 * 32 * RT * PITCH;   // one shifted copy of a dY row: [part][n][PITCH]
+  static constexpr int DROW = 3 * DCOPY;
+  static constexpr size_t LDS = XBYTES + 2 * (size_t)DROW;
+  static constexpr int NDY = 32 * RT * 4;              // dY staging items per step (n, 8-voxel piece)
+};
+
+constexpr int kScaleNone = 120;
+__host__ __device__ inline int scale_exp_of(float amax) {
+  if (amax != amax || amax > 3.0e38f) return 0;
+  if (!(amax > 0.f)) return 0;
+  int e;
+  frexpf(amax, &e);
+  const int s = 14 - e;
+  return s > kScaleNone ? kScaleNone : s;
+}
+
+struct HwParams {
+  ChanCat x, dy;
+  int cu, N;                 // channels / rows covered
+  int B, Z, Y, X;
+  int nnb, ncb, nseg, S;     // row blocks, channel blocks, x segments, splits
+  long long rows_per_split;  // (b, z, y) rows per split
+  int Npad, Cpad;
+  float* slab;               // [S * nseg][27][Npad][Cpad]
+  const float* amax;         // [0] = max|x|, [1] = max|dy|
+};
+
+template <int RT>
+__global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
+  using G = WGeo<RT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Xs = lds;
+  unsigned char* Ds = lds + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < WNT / 64);
+
+  int v = blockIdx.x;
+  const int nb = v % p.nnb;
+  v /= p.nnb;
+  const int cb = v % p.ncb;
+  v /= p.ncb;
+  const int seg = v % p.nseg;
+  const int split = v / p.nseg;
+  const int x0 = seg * 32;
+  const long long YX = (long long)p.Y * p.X, ZYX = YX * p.Z;
+
+  const float mx = ldexpf(1.f, scale_exp_of(p.amax[0])), md = ldexpf(1.f, scale_exp_of(p.amax[1]));
+
+  // ---- staging role of this thread (fixed for the whole kernel)
+  //   waves 0..5: X item  = (plane dz 0..2, channel 0..31, piece q 0..3)
+  //   waves 6..9: dY item = (row n, piece q), 32 * RT * 4 of them
+  const bool is_x = wave < 6;
+  int it_c = 0, it_q = 0, it_dz = 0, it_n = 0;
+  const float* src = nullptr;      // channel / row base of sample 0 (per lane)
+  long long src_b = 0;             // elements between samples
+  bool it_on = false;
+  if (is_x) {
+    it_dz = tid / 128, it_c = (tid % 128) / 4, it_q = tid & 3;
+    const int c = cb * 32 + it_c;
+    if (c < p.cu) {
+      const int si = cat_find(p.x, c);
+      src = cat_ptr(p.x, si) + (long long)(c - cat_cbeg(p.x, si)) * ZYX;
+      src_b = cat_bstride(p.x, si);
+      it_on = x0 + 8 * it_q < p.X;
+    }
+  } else {
+    const int i = tid - 384;
+    if (i < G::NDY) {
+      it_n = i / 4, it_q = i & 3;
+      const int n = nb * (32 * RT) + it_n;
+      if (n < p.N) {
+        const int si = cat_find(p.dy, n);
+        src = cat_ptr(p.dy, si) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX;
+        src_b = cat_bstride(p.dy, si);
+        it_on = x0 + 8 * it_q < p.X;
+      }
+    }
+  }
+  const bool stager = is_x || (tid - 384) < G::NDY;
+  const int xq = x0 + 8 * it_q;
+  float pv[10];   // piece: elements -1 .. 8 (X items use 0..7)
+#pragma unroll
+  for (int j = 0; j < 10; j++) pv[j] = 0.f;
+  // loads the piece of row (b, z, y) into pv (zeros when the row is outside the grid)
+  auto load_piece = [&](const int b, const int z, const int y) {
+    const bool ok = it_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
+    if (ok) {
+      const float* r = src + (long long)b * src_b + (long long)z * YX + (long long)y * p.X + xq;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
+      pv[1] = a.x, pv[2] = a.y, pv[3] = a.z, pv[4] = a.w, pv[5] = c4.x, pv[6] = c4.y, pv[7] = c4.z, pv[8] = c4.w;
+      if (!is_x) {
+        pv[0] = xq > 0 ? r[-1] : 0.f;
+        pv[9] = xq + 8 < p.X ? r[8] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; j++) pv[j] = 0.f;
+    }
+  };
+  auto split8 = [&](const int off, const float mult, h8& hi, h8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float s = pv[off + j] * mult;
+      const _Float16 a = (_Float16)s;
+      hi[j] = a;
+      lo[j] = (_Float16)(s - (float)a);
+    }
+  };
+  // X row (plane slot, y slot) / dY buffer addresses
+  auto write_piece = [&](const int yslot_x, const int dbuf, const float dsign) {
+    if (!stager) return;
+    if (is_x) {
+      h8 hi, lo;
+      split8(1, mx, hi, lo);
+      unsigned char* d = Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16;
+      *reinterpret_cast<h8*>(d) = hi;
+      *reinterpret_cast<h8*>(d + 32 * PITCH) = lo;
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < 3; cp++) {   // copy cp holds dY[x' - cp + 1]: element j of the piece = pv[1 + j - cp + 1]
+        h8 hi, lo;
+        split8(2 - cp, md * dsign, hi, lo);
+        unsigned char* d = Ds + dbuf * G::DROW + cp * G::DCOPY + it_n * PITCH + it_q * 16;
+        *reinterpret_cast<h8*>(d) = hi;
+        *reinterpret_cast<h8*>(d + 32 * RT * PITCH) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[3][RT];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[k][i][r] = 0.f;
+  float acc_sign = 1.f;
+  const int kz = wave / 3, ky = wave - kz * 3;   // (waves 9: no taps)
+  const int fr = (lane & 31) * PITCH + (lane >> 5) * 16;
+
+  // ---- rows of this split
+  const long long rows_total = (long long)p.B * p.Z * p.Y;
+  long long r0 = (long long)split * p.rows_per_split, r1 = r0 + p.rows_per_split;
+  if (r1 > rows_total) r1 = rows_total;
+  while (r0 < r1) {
+    const long long plane = r0 / p.Y;                 // (b, z)
+    const int b = (int)(plane / p.Z), z = (int)(plane - (long long)b * p.Z);
+    const int ya = (int)(r0 - plane * p.Y);
+    const long long pend = (plane + 1) * p.Y;
+    const int yb = (int)((r1 < pend ? r1 : pend) - plane * p.Y);
+    // step t: write what was loaded in step t-1 (X rows t+2, dY row t+1), load (X rows t+3, dY row t+2), multiply row t
+    for (int t = ya - 4; t < yb; t++) {
+      if (t > ya - 4) {
+        const long long rr = plane * p.Y + (t + 1);
+        write_piece((t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
+      }
+      if (is_x)
+        load_piece(b, z + it_dz - 1, t + 3);
+      else
+        load_piece(b, z, (t + 2 >= ya && t + 2 < yb) ? t + 2 : -1);
+      if (t >= ya && wave < 9) {
+        const long long rr = plane * p.Y + t;
+        const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
+        if (sgn != acc_sign) {   // (wave-uniform) sign alternation, see the header
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+              for (int r = 0; r < 16; r++) acc[k][i][r] = -acc[k][i][r];
+          acc_sign = sgn;
+        }
+        const unsigned char* xb = Xs + (kz * 4 + ((t + ky - 1) & 3)) * XROW + fr;
+        const unsigned char* db = Ds + (t & 1) * G::DROW + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          h8 bh = *reinterpret_cast<const h8*>(xb + ks * 32), bl = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+              const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
+              const h8 ah = *reinterpret_cast<const h8*>(a), al = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
+              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[k][i], 0, 0, 0);
+              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[k][i], 0, 0, 0);
+              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k][i], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+    }
+    r0 = plane * p.Y + yb;
+  }
+
+  // ---- partial block -> slab[split][tap][n][c]
+  if (wave < 9) {
+    const int c = cb * 32 + (lane & 31);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int tap = (kz * 3 + ky) * 3 + k;
+      float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
+#pragma unroll
+      for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int n = nb * (32 * RT) + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+          out[(long long)n * p.Cpad + c] = acc[k][i][r] * acc_sign;
+        }
+    }
+  }
+}
+
+// dW[n][c][tap] = 2^-(sx+sd) * sum_s slab[s][tap][n][c]; one thread per output, c fastest (coalesced slab reads)
+__global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int N,
+                                                            int cu, int ldc, int Npad, int Cpad, const float* amax) {
+  const float mult = ldexpf(1.f, -(scale_exp_of(amax[0]) + scale_exp_of(amax[1])));
+  const long long plane = (long long)Npad * Cpad;
+  const long long total = (long long)N * cu * 27;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % cu);
+    const long long r = e / cu;
+    const int n = (int)(r % N), tap = (int)(r / N);
+    const float* s0 = slab + (long long)tap * plane + (long long)n * Cpad + c;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {   // fixed order: deterministic
+      const float v0 = s0[(long long)k * 27 * plane], v1 = s0[(long long)(k + 1) * 27 * plane];
+      const float v2 = s0[(long long)(k + 2) * 27 * plane], v3 = s0[(long long)(k + 3) * 27 * plane];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < S; k++) s += s0[(long long)k * 27 * plane];
+    dw[((long long)n * ldc + c) * 27 + tap] = s * mult;
+  }
+}
+
+__global__ __launch_bounds__(256) void hw_absmax_kernel(const float* __restrict__ x, long long n, unsigned* slot) {
+  float m = 0.f;
+  const long long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 q = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
+struct HwPlan {
+  int rt, nnb, ncb, nseg, S, Npad, Cpad;
+  long long rows_per_split;
+};
+
+HwPlan hw_plan(const sr3d_conv_desc_t* d, int n_total, int c_used) {
+  HwPlan g;
+  g.rt = n_total > 32 ? 2 : 1;
+  g.nnb = ceil_div(n_total, 32 * g.rt), g.ncb = ceil_div(c_used, 32), g.nseg = ceil_div(d->X, 32);
+  g.Npad = g.nnb * 32 * g.rt, g.Cpad = g.ncb * 32;
+  const long long rows = (long long)d->B * d->Z * d->Y;
+  const long long cols = (long long)g.nnb * g.ncb * g.nseg;
+  // 2 .. 6 rounds over the 256 CUs (one workgroup per CU), the count that leaves the last round fullest; at least 24
+  // rows per split (4 warm-up steps per plane segment)
+  long long S = 1;
+  double best = -1.0;
+  const long long smax = rows / 24 > 0 ? rows / 24 : 1;
+  for (long long s = (512 + cols - 1) / cols; s <= (1536 + cols - 1) / cols && s <= 96; s++) {
+    const long long sc = s < 1 ? 1 : (s > smax ? smax : s);
+    const double wgs = (double)cols * sc, fill = wgs / (256.0 * (double)((long long)(wgs + 255) / 256));
+    if (fill > best + 1e-3) best = fill, S = sc;
+  }
+  g.rows_per_split = (rows + S - 1) / S;
+  g.S = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
+  return g;
+}
+
+}  // namespace
+
+// slab + 256 bytes for the two maxima
+size_t sr3d_hwgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used) {
+  const HwPlan g = hw_plan(d, n_total, c_used);
+  return 256 + (size_t)g.S * g.nseg * 27 * g.Npad * g.Cpad * 4;
+}
+
+bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy) {
+  if (d->stride != 1 || d->X % 8 != 0) return false;
+  for (int i = 0; i < x.n; i++)
+    if (reinterpret_cast<uintptr_t>(x.ptr[i]) & 15) return false;
+  for (int i = 0; i < dy.n; i++)
+    if (reinterpret_cast<uintptr_t>(dy.ptr[i]) & 15) return false;
+  return true;
+}
+
+int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw, float* ws,
+                hipStream_t st) {
+  const HwPlan g = hw_plan(d, n_total, c_used);
+  unsigned* amax = (unsigned*)ws;
+  SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
+  const long long vox = (long long)d->Z * d->Y * d->X;
+  {
+    SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
+    for (int i = 0; i < x.n; i++) {
+      const long long n = (long long)d->B * x.bstride[i];
+      const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+      hipLaunchKernelGGL(hw_absmax_kernel, dim3(blocks), dim3(256), 0, st, x.ptr[i], n, amax);
+    }
+    for (int i = 0; i < dy.n; i++) {
+      const long long n = (long long)d->B * dy.bstride[i];
+      const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+      hipLaunchKernelGGL(hw_absmax_kernel, dim3(blocks), dim3(256), 0, st, dy.ptr[i], n, amax + 1);
+    }
+    SR3D_HIP(hipGetLastError());
+  }
+  HwParams p{};
+  p.x = x, p.dy = dy, p.cu = c_used, p.N = n_total;
+  p.B = d->B, p.Z = d->Z, p.Y = d->Y, p.X = d->X;
+  p.nnb = g.nnb, p.ncb = g.ncb, p.nseg = g.nseg, p.S = g.S, p.rows_per_split = g.rows_per_split;
+  p.Npad = g.Npad, p.Cpad = g.Cpad;
+  p.slab = ws + 64, p.amax = (const float*)amax;
+  const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
+  SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
+  static thread_local bool configured = false;
+  if (!configured) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGeo<2>::LDS));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGeo<1>::LDS));
+    configured = true;
+  }
+  (void)vox;
+  {
+    SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
+    if (g.rt == 2)
+      hipLaunchKernelGGL(hwgrad_kernel<2>, dim3((unsigned)nwg), dim3(WNT), WGeo<2>::LDS, st, p);
+    else
+      hipLaunchKernelGGL(hwgrad_kernel<1>, dim3((unsigned)nwg), dim3(WNT), WGeo<1>::LDS, st, p);
+    SR3D_HIP(hipGetLastError());
+  }
+  SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
+  const long long total = (long long)n_total * c_used * 27;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, n_total, c_used,
+                     d->Cin, g.Npad, g.Cpad, (const float*)amax);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}

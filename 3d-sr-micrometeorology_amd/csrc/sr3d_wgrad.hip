@@ -557,6 +557,20 @@ inline size_t wino_wgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
   if (cu < d->Cin) bytes += sr3d_wgrad_few_ws_bytes(d, n_total, d->Cin - cu);
   return bytes;
 }
+// split-f16 weight gradient (sr3d_hwgrad.hip): stride-1 layers on grids that fill the chip (SR3D_SPLIT_F16, see
+// sr3d_hconv.hip: 0 off, 1 auto, 2 always)
+inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
+  const int mode = sr3d_hconv_mode();
+  if (mode == 0 || d->stride != 1 || d->Cin < 32 || n_total < 16 || d->X % 8 != 0) return false;
+  if (mode == 2) return true;
+  return (long long)d->B * d->Z * d->Y * d->X >= 500000;
+}
+inline size_t hwgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
+  const int cu = wino_wgrad_c_used(d);
+  size_t bytes = align256(sr3d_hwgrad_ws_bytes(d, n_total, cu));
+  if (cu < d->Cin) bytes += sr3d_wgrad_few_ws_bytes(d, n_total, d->Cin - cu);
+  return bytes;
+}
 inline bool wino_wgrad_slices_ok(const sr3d_slice_t* dy_srcs, int n_dy) {
   for (int i = 0; i < n_dy; i++)
     if (dy_srcs[i].channels % 4 || ((uintptr_t)dy_srcs[i].ptr & 7)) return false;
@@ -698,6 +712,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
   size_t bytes = (size_t)pl.S * pl.Npad * pl.Jpad * 4;
   if (use_smalln(d, n_total, 1)) bytes = std::max(bytes, (size_t)smalln_plan(d).S * d->Cin * 108 * 4);
   if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, wino_wgrad_total_ws(d, n_total));
+  if (use_hwgrad(d, n_total)) bytes = std::max(bytes, hwgrad_total_ws(d, n_total));
   return bytes;
 }
 
@@ -735,6 +750,25 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
                        (const float*)workspace, (float*)dw, sp.S, n_total, d->Cin);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
+  }
+  if (use_hwgrad(d, n_total)) {
+    ChanCat xc, dc;
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
+    if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
+    for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+    if (sr3d_hwgrad_ok(d, xc, dc)) {
+      SR3D_CHECK(workspace_bytes >= hwgrad_total_ws(d, n_total), SR3D_E_WORKSPACE,
+                 "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+      const int cu = wino_wgrad_c_used(d);
+      if (int rc = sr3d_hwgrad(d, xc, dc, n_total, cu, (float*)dw, (float*)workspace, (hipStream_t)stream)) return rc;
+      if (cu < d->Cin) {
+        float* ws2 = (float*)((char*)workspace + align256(sr3d_hwgrad_ws_bytes(d, n_total, cu)));
+        return sr3d_wgrad_few(d, dc, n_total, xc, cu, d->Cin - cu, (float*)dw, (long long)d->Cin * 27, ws2,
+                              (hipStream_t)stream);
+      }
+      return SR3D_OK;
+    }
   }
   if (use_wino_wgrad(d, n_total) && wino_wgrad_slices_ok(dy_srcs, n_dy)) {
     SR3D_CHECK(workspace_bytes >= wino_wgrad_total_ws(d, n_total), SR3D_E_WORKSPACE,
