@@ -563,7 +563,10 @@ inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
   const int mode = sr3d_hconv_mode();
   if (mode == 0 || d->stride != 1 || d->Cin < 32 || n_total < 16 || d->X % 8 != 0) return false;
   if (mode == 2) return true;
-  return (long long)d->B * d->Z * d->Y * d->X >= 500000;
+  // measured against the Winograd-domain kernel: faster from U-Net level 2 up (128 k voxels), and on level 3 for the
+  // 2056-row layers; slower on the 256-row layers of levels 3-4
+  const long long vox = (long long)d->B * d->Z * d->Y * d->X;
+  return vox >= 100000 || (n_total >= 1024 && vox >= 16000);
 }
 inline size_t hwgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
   const int cu = wino_wgrad_c_used(d);
