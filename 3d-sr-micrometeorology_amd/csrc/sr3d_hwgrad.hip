@@ -208,19 +208,32 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         }
         const unsigned char* xb = Xs + (kz * 4 + ((t + ky - 1) & 3)) * XROW + fr;
         const unsigned char* db = Ds + (t & 1) * G::DROW + fr;
+        // 2 K-steps x 3 copies x RT row tiles = 6 * RT (A pair, B pair) products; the A pair of product j+1 is read
+        // before the MFMAs of product j are issued
+        constexpr int NP = 6 * RT;
+        h8 fa[2][2], fb[2][2];   // [buffer][hi | lo]
+        auto load_a = [&](const int j, const int buf) {
+          const int ks = j / (3 * RT), k = (j / RT) % 3, i = j % RT;
+          const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
+          fa[buf][0] = *reinterpret_cast<const h8*>(a);
+          fa[buf][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
+        };
+        auto load_b = [&](const int ks) {
+          fb[ks][0] = *reinterpret_cast<const h8*>(xb + ks * 32);
+          fb[ks][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
+        };
+        load_b(0);
+        load_a(0, 0);
+        load_b(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-          h8 bh = *reinterpret_cast<const h8*>(xb + ks * 32), bl = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int i = 0; i < RT; i++) {
-              const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
-              const h8 ah = *reinterpret_cast<const h8*>(a), al = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
-              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[k][i], 0, 0, 0);
-              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[k][i], 0, 0, 0);
-              acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k][i], 0, 0, 0);
-            }
+        for (int j = 0; j < NP; j++) {
+          if (j + 1 < NP) load_a(j + 1, (j + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int ks = j / (3 * RT), k = (j / RT) % 3, i = j % RT;
+          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][1], acc[k][i], 0, 0, 0);
+          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][1], fb[ks][0], acc[k][i], 0, 0, 0);
+          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][0], acc[k][i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();

@@ -113,6 +113,35 @@ def test_split_f16_stride2_layers_vs_fp64(eng, forced, cs, cout, grid, kind, sca
         assert relerr(wgd.grad, wg.grad) < TOL
 
 
+# the split-f16 weight gradient (csrc/sr3d_hwgrad.hip) takes stride-1 layers with X % 8 == 0: 32-row and 64-row
+# workgroups, a last row block with 2 rows, 1-4 input channels beyond a multiple of 32 (few-channel kernel next to it),
+# a partial last channel block, two dY slices (gated), more than one x segment, several splits, batch 2
+@pytest.mark.parametrize("cs,cout,grid,kind", [
+    ([64], 24, (4, 12, 32), "plain"),
+    ([32, 1, 33], 130, (5, 9, 72), "plain"),
+    ([40], 64, (7, 30, 48), "plain"),
+    ([64, 2], 36, (3, 26, 40), "gated"),
+])
+def test_split_f16_weight_gradient_vs_fp64(eng, forced, cs, cout, grid, kind):
+    xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, 1.0, seed=3 * sum(cs) + cout)
+    dev = lambda t: t.detach().float().to(DEV)   # noqa: E731
+    grads = []
+    for _ in range(2):
+        xd = [dev(x).requires_grad_(x.requires_grad) for x in xs]
+        wfd, wgd, bd = dev(wf).requires_grad_(True), dev(wg).requires_grad_(True), dev(bias).requires_grad_(True)
+        if kind == "gated":
+            y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act="relu", stride=1)
+        else:
+            y = eng.ops.conv3d_act(xd, wfd, bd, act="lrelu", stride=1)
+        y.backward(dev(gy))
+        grads.append((wfd.grad.clone(), wgd.grad.clone() if kind == "gated" else None))
+    assert relerr(grads[0][0], wf.grad) < TOL
+    if kind == "gated":
+        assert relerr(grads[0][1], wg.grad) < TOL
+        assert torch.equal(grads[0][1], grads[1][1])
+    assert torch.equal(grads[0][0], grads[1][0])          # fixed-order split-K sum: bit-reproducible
+
+
 def test_split_f16_unshuffle_epilogue_matches_the_fp32_kernel(eng, monkeypatch):
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(2, 33, 5, 7, 33, generator=g) - 0.5).to(DEV)
