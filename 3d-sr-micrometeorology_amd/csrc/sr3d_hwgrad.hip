@@ -8,8 +8,9 @@
 // element off a 16-byte boundary -- so the smaller operand (dY) is staged three times, shifted by -1, 0, +1, and every
 // fragment is one aligned ds_read_b128.
 //
-// Workgroup = 10 waves: an (n-block of 32 * RT rows) x (c-block of 32 channels) x (x segment of 32 voxels) x (a range
-// of (b, z, y) rows, split-K).  Wave w < 9 owns the taps (kz, ky) = (w / 3, w % 3) x 3 kx: 3 * RT accumulator tiles.
+// Workgroup = 12 waves: an (n-block of 32 * RT rows) x (c-block of 32 channels) x (x segment of 32 voxels) x (a range
+// of (b, z, y) rows, split-K).  Waves 0..8 own the taps (kz, ky) = (w / 3, w % 3) x kx 0, 1; waves 9..11 kx = 2 of three
+// (kz, ky) groups each (balanced over the four SIMDs, see the kernel).
 // It marches along y: per step ONE new X row of each of the 3 z planes (4 y slots per plane in LDS) and one dY row
 // (3 shifted copies, double-buffered) are staged, by waves 0-5 (X) and 6-9 (dY), one 8-voxel piece per thread,
 // loaded a step ahead into registers, then scaled, split and written; one barrier per step.
@@ -22,11 +23,13 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int WNT = 640;
+constexpr int WNT = 768;
 constexpr int PITCH = 80;                          // bytes per 32-voxel fp16 row in LDS (64 + 16: conflict-free b128)
 constexpr int XROW = 2 * 32 * PITCH;               // one X row: [part][c 32][PITCH]
 constexpr int XBYTES = 12 * XROW;                  // 3 planes x 4 y slots
@@ -163,16 +166,24 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     }
   };
 
-  f32x16 acc[3][RT];
+  // The whole marching loop exists once per wave role (compile-time FEW): with one loop and a run-time role the
+  // register allocator shuffled the accumulators between the two MFMA sections and spilled 436 bytes.
+  auto run = [&](auto few_tag) {
+  constexpr bool FEW = decltype(few_tag)::value;
+  f32x16 acc[FEW ? 3 : 2][RT];
 #pragma unroll
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < (FEW ? 3 : 2); k++)
 #pragma unroll
     for (int i = 0; i < RT; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[k][i][r] = 0.f;
   float acc_sign = 1.f;
-  const int kz = wave / 3, ky = wave - kz * 3;   // (waves 9: no taps)
+  // Accumulator slots.  The 27 taps are 9 (kz, ky) groups x 3 kx; 9 waves with a group each would sit 3-2-2-2 on the four
+  // SIMDs (75 % of the matrix pipes busy at best).  So: waves 0..8 own group w with kx = 0, 1 (2 * RT tiles), waves 9..11
+  // own kx = 2 of the groups 3(w-9) .. +2 (3 * RT tiles): 12 / 14 / 14 / 14 tiles per SIMD.
+  const int g0 = FEW ? 3 * (wave - 9) : wave;
   const int fr = (lane & 31) * PITCH + (lane >> 5) * 16;
+  auto xrow = [&](const int g, const int t) { return Xs + ((g / 3) * 4 + ((t + (g % 3) - 1) & 3)) * XROW + fr; };
 
   // ---- rows of this split
   const long long rows_total = (long long)p.B * p.Z * p.Y;
@@ -194,59 +205,88 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         load_piece(b, z + it_dz - 1, t + 3);
       else
         load_piece(b, z, (t + 2 >= ya && t + 2 < yb) ? t + 2 : -1);
-      if (t >= ya && wave < 9) {
+      if (t >= ya) {
         const long long rr = plane * p.Y + t;
         const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
         if (sgn != acc_sign) {   // (wave-uniform) sign alternation, see the header
 #pragma unroll
-          for (int k = 0; k < 3; k++)
+          for (int k = 0; k < (FEW ? 3 : 2); k++)
 #pragma unroll
             for (int i = 0; i < RT; i++)
 #pragma unroll
               for (int r = 0; r < 16; r++) acc[k][i][r] = -acc[k][i][r];
           acc_sign = sgn;
         }
-        const unsigned char* xb = Xs + (kz * 4 + ((t + ky - 1) & 3)) * XROW + fr;
         const unsigned char* db = Ds + (t & 1) * G::DROW + fr;
-        // 2 K-steps x 3 copies x RT row tiles = 6 * RT (A pair, B pair) products; the A pair of product j+1 is read
-        // before the MFMAs of product j are issued
-        constexpr int NP = 6 * RT;
-        h8 fa[2][2], fb[2][2];   // [buffer][hi | lo]
-        auto load_a = [&](const int j, const int buf) {
-          const int ks = j / (3 * RT), k = (j / RT) % 3, i = j % RT;
-          const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
-          fa[buf][0] = *reinterpret_cast<const h8*>(a);
-          fa[buf][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
-        };
-        auto load_b = [&](const int ks) {
-          fb[ks][0] = *reinterpret_cast<const h8*>(xb + ks * 32);
-          fb[ks][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
-        };
-        load_b(0);
-        load_a(0, 0);
-        load_b(1);
+        if constexpr (!FEW) {
+          // one X row, the dY copies of kx = 0, 1: 2 K-steps x 2 copies x RT row tiles products; the A pair of
+          // product j+1 is read before the MFMAs of product j are issued
+          const unsigned char* xb = xrow(g0, t);
+          constexpr int NP = 4 * RT;
+          h8 fa[2][2], fb[2][2];   // [buffer][hi | lo]
+          auto load_a = [&](const int j, const int buf) {
+            const int ks = j / (2 * RT), k = (j / RT) % 2, i = j % RT;
+            const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
+            fa[buf][0] = *reinterpret_cast<const h8*>(a);
+            fa[buf][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
+          };
+          auto load_b = [&](const int ks) {
+            fb[ks][0] = *reinterpret_cast<const h8*>(xb + ks * 32);
+            fb[ks][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
+          };
+          load_b(0);
+          load_a(0, 0);
+          load_b(1);
 #pragma unroll
-        for (int j = 0; j < NP; j++) {
-          if (j + 1 < NP) load_a(j + 1, (j + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          const int ks = j / (3 * RT), k = (j / RT) % 3, i = j % RT;
-          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][1], acc[k][i], 0, 0, 0);
-          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][1], fb[ks][0], acc[k][i], 0, 0, 0);
-          acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][0], acc[k][i], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < NP; j++) {
+            if (j + 1 < NP) load_a(j + 1, (j + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = j / (2 * RT), k = (j / RT) % 2, i = j % RT;
+            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][1], acc[k][i], 0, 0, 0);
+            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][1], fb[ks][0], acc[k][i], 0, 0, 0);
+            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][0], acc[k][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          // three X rows, the dY copy of kx = 2 (shared by the three)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) {
+            h8 fa[RT][2];
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+              const unsigned char* a = db + 2 * G::DCOPY + i * 32 * PITCH + ks * 32;
+              fa[i][0] = *reinterpret_cast<const h8*>(a);
+              fa[i][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {   // (one B pair at a time: the wave has 170 registers)
+              const unsigned char* xb = xrow(g0 + k, t);
+              const h8 bh = *reinterpret_cast<const h8*>(xb + ks * 32), bl = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
+#pragma unroll
+              for (int i = 0; i < RT; i++) {
+                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], bl, acc[k][i], 0, 0, 0);
+                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], bh, acc[k][i], 0, 0, 0);
+                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], bh, acc[k][i], 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
       }
-      __syncthreads();
+      // (not __syncthreads(): that would drain vmcnt and expose the latency of the loads issued above in every step;
+      // they are only needed by write_piece of the next step, where hipcc waits for them itself)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
     r0 = plane * p.Y + yb;
   }
 
-  // ---- partial block -> slab[split][tap][n][c]
-  if (wave < 9) {
+  // ---- partial block -> slab[split, segment][tap][n][c]
+  {
     const int c = cb * 32 + (lane & 31);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int tap = (kz * 3 + ky) * 3 + k;
+    for (int k = 0; k < (FEW ? 3 : 2); k++) {
+      const int tap = FEW ? (g0 + k) * 3 + 2 : g0 * 3 + k;
       float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
 #pragma unroll
       for (int i = 0; i < RT; i++)
@@ -257,6 +297,11 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         }
     }
   }
+  };
+  if (wave >= 9)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
 }
 
 // dW[n][c][tap] = 2^-(sx+sd) * sum_s slab[s][tap][n][c]; one thread per output, c fastest (coalesced slab reads)

@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-KERNELS = {"hconv": "hconv_kernel", "igemm_s1": "wino_kernel", "wgrad": "wino_wgrad_kernel", "igemm_s2": "igemm_kernel<2,",
+KERNELS = {"hwgrad": "hwgrad_kernel", "hconv_s2": "hconv_s2_kernel", "hconv": "hconv_kernel", "igemm_s1": "wino_kernel", "wgrad": "wino_wgrad_kernel", "igemm_s2": "igemm_kernel<2,",
            "igemm_bwd_s2": "igemm_kernel<1, 0,", "wgrad_direct": "::wgrad_kernel<"}
 
 
