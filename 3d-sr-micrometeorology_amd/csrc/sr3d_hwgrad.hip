@@ -359,7 +359,9 @@ HwPlan hw_plan(const sr3d_conv_desc_t* d, int n_total, int c_used) {
   long long S = 1;
   double best = -1.0;
   const long long smax = rows / 24 > 0 ? rows / 24 : 1;
-  for (long long s = (512 + cols - 1) / cols; s <= (1536 + cols - 1) / cols && s <= 96; s++) {
+  const long long s_hi = (1536 + cols - 1) / cols < 96 ? (1536 + cols - 1) / cols : 96;
+  const long long s_lo = (512 + cols - 1) / cols < s_hi ? (512 + cols - 1) / cols : s_hi;
+  for (long long s = s_lo; s <= s_hi; s++) {
     const long long sc = s < 1 ? 1 : (s > smax ? smax : s);
     const double wgs = (double)cols * sc, fill = wgs / (256.0 * (double)((long long)(wgs + 255) / 256));
     if (fill > best + 1e-3) best = fill, S = sc;
