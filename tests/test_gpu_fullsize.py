@@ -211,6 +211,42 @@ def test_batch4_unshuffle_conv_beyond_2g_elements(eng):
     assert relerr(bias.grad, bcr.grad) < TOL
 
 
+@pytest.mark.parametrize("cs,cout,stride,gated,B,grid", [
+    ([64], 64, 1, False, 1, FULL),            # up1.convs.1: 80 workgroup rounds, 10 x segments, 26 splits
+    ([64, 1], 128, 2, True, 1, FULL),         # down1.convs.0 (stride 2, gated, mask slice)
+    ([128, 1], 136, 1, False, 4, (40, 160, 160)),   # batch 4 at level 1: sample offsets, a 2-row last block, few-channel kernel
+])
+def test_split_f16_and_fp32_engines_agree_at_full_size(eng, monkeypatch, cs, cout, stride, gated, B, grid):
+    """the split-f16 kernels (forward, input gradient, weight gradient; default dispatch) against the fp32 MFMA kernels
+    (SR3D_SPLIT_F16=0) on the benchmark's own launch shapes; no activation kinks, so both are the same smooth function"""
+    g = torch.Generator().manual_seed(31 + cout)
+    xs = [(torch.rand(B, c, *grid, generator=g) - 0.5) if c > 1 else (torch.rand(B, 1, *grid, generator=g) > 0.2).float()
+          for c in cs]
+    cin = sum(cs)
+    wf = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    wg = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    out = {}
+    gy = None
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SR3D_SPLIT_F16", mode)
+        xd = [x.to(DEV).requires_grad_(x.shape[1] > 1) for x in xs]
+        wfd, wgd, bd = (t.to(DEV).requires_grad_(True) for t in (wf, wg, bias))
+        if gated:
+            y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act=None, stride=stride)
+        else:
+            y = eng.ops.conv3d_act(xd, wfd, bd, act=None, stride=stride)
+        if gy is None:
+            gy = torch.rand(y.shape, generator=torch.Generator(device=DEV).manual_seed(5), device=DEV) - 0.5
+        y.backward(gy)
+        torch.cuda.synchronize()
+        out[mode] = [y.detach(), xd[0].grad, wfd.grad, bd.grad] + ([wgd.grad] if gated else [])
+        del xd, y
+    for a, b in zip(out["1"], out["0"]):
+        assert relerr(a, b) < 5e-6
+    assert not torch.equal(out["1"][0], out["0"][0])     # (two different engines did run)
+
+
 def test_fused_adam_65m_parameters(eng):
     n = 65_472_736
     g = torch.Generator().manual_seed(1)
