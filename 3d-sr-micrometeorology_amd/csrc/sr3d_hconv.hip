@@ -28,7 +28,7 @@
 //             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
 //   weights   split + packed once per call: [row block][chunk][kz][ky][kx][part][row tile][64 lanes][8 ch]; one
 //             (kz, ky) phase (3 taps, 12 KB) arrives by LDS-DMA while the previous one is multiplied (two buffers)
-#include "sr3d_common.h"
+#include "sr3d_split_f16.h"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -40,7 +40,6 @@
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int HKC = 16;                        // channels per chunk
 constexpr int HHZ = 4, HHY = 6, HHX = 34;      // halo of the 2 x 4 x 32 voxel tile
@@ -59,38 +58,6 @@ struct HGeo {
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
-typedef __attribute__((address_space(3))) void* lds_p;
-
-__device__ __forceinline__ float hact(float v, int act) {
-  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
-  return v;
-}
-
-// exponent s with amax * 2^s in [2^13, 2^14); kScaleNone for amax = 0 ("no opinion"), 0 for inf / NaN
-constexpr int kScaleNone = 120;
-__device__ __forceinline__ int scale_exp(float amax) {
-  if (amax != amax || amax > 3.0e38f) return 0;
-  if (!(amax > 0.f)) return kScaleNone;
-  int e;
-  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
-  const int s = 14 - e;
-  return s > kScaleNone ? kScaleNone : s;
-}
-
-// 16 bytes per lane, global -> LDS, buffer form.  (Device pass only: the host pass of hipcc rejects the 16-byte size
-// of this builtin -- it checks it against the host's feature set -- and then drops the kernel's stub without a message.)
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_p dst, int voffset) {
-#if __HIP_DEVICE_COMPILE__
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voffset, 0, 0, 0);
-#endif
-}
-
-// keeps a wave-uniform value in a scalar register and opaque to the optimiser
-template <typename T>
-__device__ __forceinline__ void pin_scalar(T& x) {
-  asm volatile("" : "+s"(x));
-}
 
 template <int RT>
 __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
@@ -121,8 +88,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const long long ZYX = (long long)p.Z * p.Y * p.X;
   const int chan_bytes = (int)(ZYX * 4);
 
-  int sw = scale_exp(*p.absmax_w);
-  if (sw == kScaleNone) sw = 0;
+  int sw = split_scale_exp(*p.absmax_w);
+  if (sw == kSplitScaleNone) sw = 0;
   // exchange slots for the wave maxima [chunk parity][wave]: in the padding behind the 816 voxels of halo plane 0
   float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
 
@@ -148,13 +115,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
 #undef SR3D_SLICE_BASE
   int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
-  pin_scalar(sb0), pin_scalar(sb1), pin_scalar(sb2), pin_scalar(sb3);
-  pin_scalar(cb0), pin_scalar(cb1), pin_scalar(cb2), pin_scalar(cb3);
+  split_pin_scalar(sb0), split_pin_scalar(sb1), split_pin_scalar(sb2), split_pin_scalar(sb3);
+  split_pin_scalar(cb0), split_pin_scalar(cb1), split_pin_scalar(cb2), split_pin_scalar(cb3);
   auto slice_of = [&](const int gc) { return (gc >= cb1) + (gc >= cb2) + (gc >= cb3); };
   // (mask arithmetic instead of selects: hipcc turns a select chain over four values into a lookup table in scratch)
   unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
   int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
-  pin_scalar(dsb1), pin_scalar(dsb2), pin_scalar(dsb3), pin_scalar(dcb1), pin_scalar(dcb2), pin_scalar(dcb3);
+  split_pin_scalar(dsb1), split_pin_scalar(dsb2), split_pin_scalar(dsb3), split_pin_scalar(dcb1), split_pin_scalar(dcb2), split_pin_scalar(dcb3);
   auto chan_base = [&](const int gc) {   // gc is wave-uniform
     const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
     const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
@@ -192,10 +159,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) xmax[parity * 4 + wave] = m;
   };
-  // running scale exponent: the largest chunk magnitude seen so far decides (kScaleNone until a non-zero chunk came)
+  // running scale exponent: the largest chunk magnitude seen so far decides (kSplitScaleNone until a non-zero chunk came)
   auto next_scale = [&](const int parity, const int s_run) {
     const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
-    const int s_c = __builtin_amdgcn_readfirstlane(scale_exp(m));
+    const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
   };
   h8 chi[HNR], clo[HNR];   // halo pieces of the next chunk, split
@@ -231,7 +198,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 #pragma unroll
     for (int ii = 0; ii < (G::PIECES + 3) / 4; ii++) {
       const int i = wave + 4 * ii;
-      if (i < G::PIECES) lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
+      if (i < G::PIECES) split_lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
     }
   };
 
@@ -259,7 +226,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  int s_run = next_scale(0, kScaleNone);   // exponent of the scale the accumulators are in
+  int s_run = next_scale(0, kSplitScaleNone);   // exponent of the scale the accumulators are in
   convert(ldexpf(1.f, s_run));
   write_halo();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -353,7 +320,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 
   // ------------------------------------------------------------------ epilogue (direct 32 x 32 layout)
   // (sign: the accumulators changed sign nchunks - 1 times)
-  const float out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kScaleNone ? 0 : s_run) + sw));
+  const float out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
   const int ox = x0 + (lane & 31);
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
@@ -375,7 +342,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
             if (p.bias) f += p.bias[co];
             const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
             const float s = 1.f / (1.f + expf(-g));
-            f = hact(f, p.act);
+            f = split_act(f, p.act);
             const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
             p.y[o] = s * f;
             if (p.save_f) {
@@ -398,7 +365,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int r = 0; r < 16; r++) {
           const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
           if (n < p.N) {
-            const float val = hact(acc[i][j][r] * out_mult + p.bias[n], p.act);
+            const float val = split_act(acc[i][j][r] * out_mult + p.bias[n], p.act);
             const int f = n / p.unsh_C, c = n - f * p.unsh_C;
             const long long o = ((long long)b * p.unsh_C + c) * TZYX +
                                 ((long long)(2 * oz + (f >> 2)) * p.TY_ + (2 * oy + ((f >> 1) & 1))) * p.TX_ + (2 * ox + (f & 1));
@@ -422,7 +389,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int j = 0; j < 2; j++) {
           const int vt = 2 * wave + j;
           const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-          if (oz < p.Z && oy < p.Y) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = hact(acc[i][j][r] * out_mult + bv, p.act);
+          if (oz < p.Z && oy < p.Y) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = split_act(acc[i][j][r] * out_mult + bv, p.act);
         }
       }
   }
@@ -456,8 +423,8 @@ struct HPackParams {
 };
 
 __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
-  const int sw = scale_exp(*p.absmax_w);
-  const float w_mult = ldexpf(1.f, sw == kScaleNone ? 0 : sw);
+  const int sw = split_scale_exp(*p.absmax_w);
+  const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
   const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;   // items of 8 channels
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     // the tap runs fastest over the threads: the 27 taps of one (row, channel) are contiguous in the weight tensor, so a
@@ -514,7 +481,9 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
   }
 }
 
-int absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st) {
+}  // namespace
+
+int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st) {
   long long blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
@@ -522,6 +491,8 @@ int absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st) {
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
+
+namespace {
 
 inline void row_split(int rows, int* n2, int* n1) {   // 64-row blocks, and one last block of <= 32 rows
   const int nfull = rows / 64, rem = rows - nfull * 64;
@@ -551,9 +522,9 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
   SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
-  if (int rc = absmax_launch(w1, nw, hdr, st)) return rc;
+  if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
   if (w2 != nullptr)
-    if (int rc = absmax_launch(w2, nw, hdr, st)) return rc;
+    if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
   HPackParams p{};
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.nchunks = ceil_div(K, HKC);

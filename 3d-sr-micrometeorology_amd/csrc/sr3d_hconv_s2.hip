@@ -15,15 +15,13 @@
 //
 // Per chunk only 12 .. 96 MFMAs per wave stand against the staging of 16 x 495 values, so the pipeline is simpler
 // than at stride 1: the halo refill is not overlapped inside a workgroup; the second workgroup of the CU covers it.
-#include "sr3d_common.h"
+#include "sr3d_split_f16.h"
 
 #include <limits.h>
 #include <stdlib.h>
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void* lds_p;
 
 constexpr int HKC = 16;
 constexpr int HHY = 6, HHX = 34;               // LDS pitches of sr3d_hconv.hip; used region 3 x 5 x 33
@@ -39,30 +37,6 @@ struct SGeo {
   static constexpr size_t LDS = HBYTES + 2 * (size_t)WBUF;
 };
 static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
-
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_p dst, int voffset) {
-#if __HIP_DEVICE_COMPILE__   // (see sr3d_hconv.hip: the host pass rejects the 16-byte size)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voffset, 0, 0, 0);
-#endif
-}
-template <typename T>
-__device__ __forceinline__ void pin_scalar(T& x) {
-  asm volatile("" : "+s"(x));
-}
-constexpr int kScaleNone = 120;
-__device__ __forceinline__ int scale_exp(float amax) {
-  if (amax != amax || amax > 3.0e38f) return 0;
-  if (!(amax > 0.f)) return kScaleNone;
-  int e;
-  frexpf(amax, &e);
-  const int s = 14 - e;
-  return s > kScaleNone ? kScaleNone : s;
-}
-__device__ __forceinline__ float hact(float v, int act) {
-  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
-  return v;
-}
 
 // halo coordinate of local tap i in a dimension of parity `par` (host and device)
 //   MODE 1 (forward):  even: k = 1 at h = 1;  odd: i = 0 -> k = 0 at h = 0, i = 1 -> k = 2 at h = 1   (halo origin o0 - 1)
@@ -101,8 +75,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   const long long IZYX = (long long)p.IZ * p.IY * p.IX;
   const int chan_bytes = (int)(IZYX * 4);
 
-  int sw = scale_exp(*p.absmax_w);
-  if (sw == kScaleNone) sw = 0;
+  int sw = split_scale_exp(*p.absmax_w);
+  if (sw == kSplitScaleNone) sw = 0;
   float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
 
   // ---- staging geometry (class-independent part): halo voxel of this lane in round r
@@ -136,11 +110,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
 #undef SR3D_SLICE_BASE
   int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
-  pin_scalar(sb0), pin_scalar(sb1), pin_scalar(sb2), pin_scalar(sb3);
-  pin_scalar(cb0), pin_scalar(cb1), pin_scalar(cb2), pin_scalar(cb3);
+  split_pin_scalar(sb0), split_pin_scalar(sb1), split_pin_scalar(sb2), split_pin_scalar(sb3);
+  split_pin_scalar(cb0), split_pin_scalar(cb1), split_pin_scalar(cb2), split_pin_scalar(cb3);
   unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
   int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
-  pin_scalar(dsb1), pin_scalar(dsb2), pin_scalar(dsb3), pin_scalar(dcb1), pin_scalar(dcb2), pin_scalar(dcb3);
+  split_pin_scalar(dsb1), split_pin_scalar(dsb2), split_pin_scalar(dsb3), split_pin_scalar(dcb1), split_pin_scalar(dcb2), split_pin_scalar(dcb3);
   auto chan_base = [&](const int gc) {
     const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
     const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
@@ -182,7 +156,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   };
   auto next_scale = [&](const int parity, const int s_run) {
     const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
-    const int s_c = __builtin_amdgcn_readfirstlane(scale_exp(m));
+    const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
   };
   auto split_and_write = [&](const float in_mult) {
@@ -209,7 +183,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
 #pragma unroll
     for (int ii = 0; ii < 2; ii++) {
       const int i = wave + 4 * ii;
-      if (i < npieces) lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
+      if (i < npieces) split_lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
     }
   };
 
@@ -237,7 +211,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  int s_run = next_scale(0, kScaleNone);
+  int s_run = next_scale(0, kSplitScaleNone);
   split_and_write(ldexpf(1.f, s_run));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -312,7 +286,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   }
 
   // ------------------------------------------------------------------ epilogue
-  const float out_mult = ldexpf((NV & 1) ? 1.f : -1.f, -((s_run == kScaleNone ? 0 : s_run) + sw));
+  const float out_mult = ldexpf((NV & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
   const int ox = x0 + (lane & 31);
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
@@ -334,7 +308,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
             if (p.bias) f += p.bias[co];
             const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
             const float s = 1.f / (1.f + expf(-g));
-            f = hact(f, p.act);
+            f = split_act(f, p.act);
             const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
             p.y[o] = s * f;
             if (p.save_f) {
@@ -364,7 +338,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
           const int vt = 2 * wave + j;
           const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
           if (oz < TZ && oy < TY)
-            base[((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx)] = hact(acc[i][j][r] * out_mult + bv, p.act);
+            base[((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx)] = split_act(acc[i][j][r] * out_mult + bv, p.act);
         }
       }
   }
@@ -391,8 +365,8 @@ __host__ __device__ inline int cls_taps_before(int cls) {
 }
 
 __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p) {
-  const int sw = scale_exp(*p.absmax_w);
-  const float w_mult = ldexpf(1.f, sw == kScaleNone ? 0 : sw);
+  const int sw = split_scale_exp(*p.absmax_w);
+  const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
   // items: (row block, class, chunk, local tap, row tile, channel half, row); 27 taps over the 8 classes
   const long long total = (long long)p.nblk * p.cpc * 27 * p.RT * 64;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -461,15 +435,6 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
   }
 }
 
-__global__ __launch_bounds__(256) void absmax_w_kernel(const float* __restrict__ x, long long n, unsigned* slot) {
-  float m = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
-}
-
 inline void row_split(int rows, int* n2, int* n1) {
   const int nfull = rows / 64, rem = rows - nfull * 64;
   *n2 = nfull + (rem > 32 ? 1 : 0);
@@ -499,10 +464,9 @@ int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, c
   SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
-  const int ab = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
-  hipLaunchKernelGGL(absmax_w_kernel, dim3(ab), dim3(256), 0, st, w1, nw, hdr);
-  if (w2 != nullptr) hipLaunchKernelGGL(absmax_w_kernel, dim3(ab), dim3(256), 0, st, w2, nw, hdr);
-  SR3D_HIP(hipGetLastError());
+  if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
+  if (w2 != nullptr)
+    if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
   S2PackParams p{};
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.cpc = ceil_div(K, HKC), p.mode = mode;

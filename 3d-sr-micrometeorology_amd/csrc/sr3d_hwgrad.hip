@@ -18,7 +18,7 @@
 // The f16 MFMA's truncation bias (sr3d_hconv.hip) is cancelled by flipping the sign of the dY rows and of the
 // accumulators every 32 rows.  Partial sums per (split, x segment) go to a slab [.][tap][n][c]; a second kernel adds them
 // in a fixed order (deterministic), undoes the scaling and writes dW[n][c][tap].
-#include "sr3d_common.h"
+#include "sr3d_split_f16.h"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -27,7 +27,6 @@
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int WNT = 768;
 constexpr int PITCH = 80;                          // bytes per 32-voxel fp16 row in LDS (64 + 16: conflict-free b128)
@@ -41,14 +40,10 @@ struct WGeo {
   static constexpr int NDY = 32 * RT * 4;              // dY staging items per step (n, 8-voxel piece)
 };
 
-constexpr int kScaleNone = 120;
+// exponent of the per-tensor scale (0, i.e. no scaling, for an all-zero tensor)
 __host__ __device__ inline int scale_exp_of(float amax) {
-  if (amax != amax || amax > 3.0e38f) return 0;
-  if (!(amax > 0.f)) return 0;
-  int e;
-  frexpf(amax, &e);
-  const int s = 14 - e;
-  return s > kScaleNone ? kScaleNone : s;
+  const int s = split_scale_exp(amax);
+  return s == kSplitScaleNone ? 0 : s;
 }
 
 struct HwParams {
@@ -327,21 +322,6 @@ __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void hw_absmax_kernel(const float* __restrict__ x, long long n, unsigned* slot) {
-  float m = 0.f;
-  const long long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const f32x4 q = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
-  }
-  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
-}
-
 struct HwPlan {
   int rt, nnb, ncb, nseg, S, Npad, Cpad;
   long long rows_per_split;
@@ -396,16 +376,10 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   const long long vox = (long long)d->Z * d->Y * d->X;
   {
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
-    for (int i = 0; i < x.n; i++) {
-      const long long n = (long long)d->B * x.bstride[i];
-      const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
-      hipLaunchKernelGGL(hw_absmax_kernel, dim3(blocks), dim3(256), 0, st, x.ptr[i], n, amax);
-    }
-    for (int i = 0; i < dy.n; i++) {
-      const long long n = (long long)d->B * dy.bstride[i];
-      const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
-      hipLaunchKernelGGL(hw_absmax_kernel, dim3(blocks), dim3(256), 0, st, dy.ptr[i], n, amax + 1);
-    }
+    for (int i = 0; i < x.n; i++)
+      if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax, st)) return rc;
+    for (int i = 0; i < dy.n; i++)
+      if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 1, st)) return rc;
     SR3D_HIP(hipGetLastError());
   }
   HwParams p{};

@@ -1,0 +1,46 @@
+// Shared pieces of the split-f16 kernels (sr3d_hconv.hip, sr3d_hconv_s2.hip, sr3d_hwgrad.hip): fp32 operands as two fp16
+// halves on v_mfma_f32_32x32x16_f16.  gfx950 only.
+#pragma once
+#include "sr3d_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_p;
+
+// Exponent s with amax * 2^s in [2^13, 2^14): the largest element then splits into hi = fp16(a), lo = fp16(a - hi) with
+// |a - hi - lo| <= 2^-22 |a| and cannot overflow.  kSplitScaleNone for amax = 0 ("no opinion": running minima keep
+// their value), 0 for inf / NaN.
+constexpr int kSplitScaleNone = 120;
+__host__ __device__ inline int split_scale_exp(float amax) {
+  if (amax != amax || amax > 3.0e38f) return 0;
+  if (!(amax > 0.f)) return kSplitScaleNone;
+  int e;
+  frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  const int s = 14 - e;
+  return s > kSplitScaleNone ? kSplitScaleNone : s;
+}
+
+// 16 bytes per lane, global -> LDS, buffer form.  (The buffer form on purpose: global_load_lds is a FLAT instruction
+// touching two address spaces, and while one is pending hipcc turns every LDS wait of the wave into lgkmcnt(0).  Device
+// pass only: the host pass of hipcc rejects the 16-byte size of this builtin -- it checks it against the host's
+// feature set -- and then drops the calling kernel's stub without a message.)
+__device__ __forceinline__ void split_lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_p dst, int voffset) {
+#if __HIP_DEVICE_COMPILE__
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
+// keeps a wave-uniform value in a scalar register and opaque to the optimiser
+template <typename T>
+__device__ __forceinline__ void split_pin_scalar(T& x) {
+  asm volatile("" : "+s"(x));
+}
+
+__device__ __forceinline__ float split_act(float v, int act) {
+  if (act == SR3D_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SR3D_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  return v;
+}
+
+// max |x| of a tensor into *slot with atomicMax (bits of a non-negative float order like unsigned integers; the caller
+// zeroes the slot).  Defined in sr3d_hconv.hip.
+int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st);
