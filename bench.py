@@ -314,8 +314,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("fp32 (storage, accumulation and results; stride-1 conv products as 3 f16 MFMAs on 2-way split fp32 "
-                      "operands, error 2^-22 per operand, every parity test at 1e-5; SR3D_SPLIT_F16=0: fp32 MFMA only)"
+            "dtype": ("fp32 (storage, accumulation and results; products of the chip-filling convolutions -- forward, input "
+                      "gradient, stride-1 weight gradient -- as 3 f16 MFMAs on 2-way split fp32 operands, error 2^-22 per "
+                      "operand, every parity test at 1e-5; SR3D_SPLIT_F16=0: fp32 MFMA only)"
                       if split else "fp32"),
             "data": "synthetic",
             "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world) +
@@ -354,7 +355,7 @@ def main():
         if fp32_only is not None:
             n5 = min(args.steps, 5)
             fd = fp32_only["prof"]["igemm_s1"]
-            out["fp32_mfma_only"] = {"note": "same workload with SR3D_SPLIT_F16=0 (fp32 Winograd kernel for every stride-1 layer)",
+            out["fp32_mfma_only"] = {"note": "same workload with SR3D_SPLIT_F16=0 (fp32 MFMA kernels only: Winograd stride 1, direct stride 2)",
                                      "value": fp32_only["voxels_per_step"] * n5 / fp32_only["elapsed"], "unit": "HR voxels/s",
                                      "steps": n5, "warmup": 1, "ms_per_step": fp32_only["elapsed"] / n5 * 1e3,
                                      "loss": fp32_only["loss"],
