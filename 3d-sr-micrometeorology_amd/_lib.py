@@ -95,10 +95,11 @@ lib = _load()
 PROFILING = False   # per-kernel HIP-event timing is on (bench.py): ops then keeps every launch on ONE stream
 
 
-def profile_enable(on: bool) -> None:
-    """sr3d_profile_enable + the flag `ops` reads: kernels overlapped on two streams cannot be timed one by one"""
+def profile_enable(on) -> None:
+    """sr3d_profile_enable (0 off, 1 every family, 2 only the stride-1 convolution families) + the flag `ops` reads:
+    kernels overlapped on two streams cannot be timed one by one"""
     global PROFILING
-    check(lib.sr3d_profile_enable(1 if on else 0), "sr3d_profile_enable")
+    check(lib.sr3d_profile_enable(int(on)), "sr3d_profile_enable")
     PROFILING = bool(on)
 
 

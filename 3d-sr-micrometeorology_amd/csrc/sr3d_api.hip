@@ -45,6 +45,7 @@ std::vector<ProfRec> g_prof;
 int g_prof_next = 0;
 long long g_prof_dropped = 0;
 bool g_prof_on = false;
+bool g_prof_dominant_only = false;   // sr3d_profile_enable(2): only the stride-1 conv families are bracketed
 }  // namespace
 
 bool sr3d_prof_active() { return g_prof_on; }
@@ -52,6 +53,7 @@ bool sr3d_prof_active() { return g_prof_on; }
 void sr3d_prof_begin(int id, double work, hipStream_t st, void** token) {
   *token = nullptr;
   if (!g_prof_on) return;
+  if (g_prof_dominant_only && id != SR3D_PROF_HCONV && id != SR3D_PROF_IGEMM_S1) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_next >= (int)g_prof.size()) { g_prof_dropped++; return; }
   ProfRec* r = &g_prof[g_prof_next++];
@@ -79,6 +81,7 @@ int sr3d_profile_enable(int on) {
     }
   }
   g_prof_on = on != 0;
+  g_prof_dominant_only = on == 2;
   return SR3D_OK;
 }
 

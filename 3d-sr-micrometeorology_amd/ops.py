@@ -26,7 +26,11 @@ KINK_LOG: Optional[list] = None
 # dozen to a few hundred workgroups per kernel, fewer than the 256 CUs) they are launched on two HIP streams so that
 # together they fill the chip; on the large grids every kernel fills it alone and a second stream buys nothing.
 _SIDE_STREAMS: dict = {}
-CONCURRENT_WGRAD_MAX_VOXELS = int(os.environ.get("SR3D_CONCURRENT_WGRAD_MAX_VOXELS", str(1_100_000)))   # levels >= 1 of the 80x320x320 benchmark grid
+# Weight gradient on a second HIP stream next to the input gradient, up to this many voxels.  OFF by default since the
+# split-f16 kernels: both are then power- / LDS-bound kernels that cannot share a CU (80 + 120 KB of LDS), and running
+# them side by side made the 80x320x320 step 12-15 ms SLOWER (266 vs 279-282 ms as a hipGraph replay).  With the fp32
+# kernels (SR3D_SPLIT_F16=0) 1,100,000 was worth 2 ms.
+CONCURRENT_WGRAD_MAX_VOXELS = int(os.environ.get("SR3D_CONCURRENT_WGRAD_MAX_VOXELS", "0"))
 
 
 def _side_stream(device) -> "torch.cuda.Stream":

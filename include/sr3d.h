@@ -251,6 +251,9 @@ enum {
   SR3D_PROF_FAMILIES = 12,
   SR3D_PROF_DROPPED = 99      /* launches: records lost because the event pool was exhausted */
 };
+/* on = 1: every family; on = 2: only the stride-1 convolution families (SR3D_PROF_HCONV, SR3D_PROF_IGEMM_S1): bench.py
+ * brackets only the dominant kernel inside its timed region (48 instead of ~1100 event records per training step) and
+ * collects the other families in a separate, untimed pass; on = 0: off. */
 int sr3d_profile_enable(int on);
 int sr3d_profile_read(int kernel_id, double* ms, double* work, long long* launches);
 
