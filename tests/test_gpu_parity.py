@@ -273,6 +273,25 @@ def test_alternative_kernel_paths_in_subprocess(env):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_weight_gradient_on_the_side_stream_gives_the_same_bits(eng, monkeypatch):
+    """ops._grads_two_streams (off by default: SR3D_CONCURRENT_WGRAD_MAX_VOXELS=0): with the overlap switched on the
+    weight / bias gradients come from a second HIP stream; same kernels, same results"""
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(2, 12, 6, 10, 34, generator=g) - 0.5)
+    w = torch.randn(20, 12, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(20, generator=g) * 0.1
+    out = []
+    for limit in (0, 10 ** 9):
+        monkeypatch.setattr(eng.ops, "CONCURRENT_WGRAD_MAX_VOXELS", limit)
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        y = eng.ops.conv3d_act([xd], wd, bd, act="lrelu", stride=1)
+        y.backward(torch.ones_like(y))
+        torch.cuda.synchronize()
+        out.append((xd.grad.clone(), wd.grad.clone(), bd.grad.clone()))
+    for a, c in zip(*out):
+        assert torch.equal(a, c)
+
+
 def test_gated_conv_with_two_output_channels(eng):
     """n_dy = 2 with n_total <= 4: the weight-gradient workspace query must cover the path the call really takes"""
     import torch.nn.functional as F
