@@ -92,9 +92,17 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
 
     model = sr3d_amd.make_model(config).to(rank)
     loss_fn = sr3d_amd.make_loss(config)
-    flat = sr3d_amd.FlatAdam(model.parameters(), lr=config["train"]["lr"])
-    reducer = sr3d_amd.GradAllReducer(flat.params, flat.flat_grad, flat.offsets)
-    reducer.broadcast_parameters(flat.flat_param)   # what the DDP constructor does (train_model.py:179)
+    # engine extension (absent from the reference's YAML = off): `train: {hip_graph: true}` replays the training step as a
+    # hipGraph (src/graph.py; one GPU, no GradNorm): 5 % faster at 80x320x320, 15 % on the reference's 32x64x64 crops
+    use_graph = bool(config["train"].get("hip_graph", False)) and world_size == 1 and not use_grad_norm
+    flat = sr3d_amd.FlatAdam(model.parameters(), lr=config["train"]["lr"], capturable=use_graph)
+    reducer, graph_step = None, None
+    if use_graph:
+        from sr3d_amd.src.optim_helper import LazyGraphedStep
+        graph_step = LazyGraphedStep(model, loss_fn, flat)
+    else:
+        reducer = sr3d_amd.GradAllReducer(flat.params, flat.flat_grad, flat.offsets)
+        reducer.broadcast_parameters(flat.flat_param)   # what the DDP constructor does (train_model.py:179)
     grad_norm, optimizer = None, flat
     if use_grad_norm:
         gn = config["train"]["grad_norm"]
@@ -109,7 +117,8 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         dist.barrier()
         loss = train_ddp(dataloader=dataloaders["train"], sampler=samplers["train"], model=model, loss_fn=loss_fn,
                          optimizer=optimizer, epoch=epoch, rank=rank, world_size=world_size,
-                         num_loops=config["train"]["num_loops_train"], grad_norm=grad_norm, reducer=reducer)
+                         num_loops=config["train"]["num_loops_train"], grad_norm=grad_norm, reducer=reducer,
+                         graph_step=graph_step)
         dist.barrier()
         val_loss = test_ddp(dataloader=dataloaders["valid"], sampler=samplers["valid"], model=model, loss_fn=loss_fn,
                             epoch=epoch, rank=rank, world_size=world_size, num_loops=config["train"]["num_loops_valid"],

@@ -43,6 +43,24 @@ def _device_batches(dataloader, device, num_loops: int = 1):
             yield Xs.to(device), bs.unsqueeze(1).to(device), ys.to(device)
 
 
+class LazyGraphedStep:
+    """Engine extension (no reference counterpart): the training step as a hipGraph replay (src/graph.py) inside the
+    reference's loops.  Captured on the first batch; a batch of another shape (the last, partial one of an epoch) runs
+    eagerly.  Needs ``FlatAdam(capturable=True)``, one GPU, no GradNorm."""
+
+    def __init__(self, model, loss_fn, optimizer):
+        self.model, self.loss_fn, self.optimizer, self.graphed = model, loss_fn, optimizer, None
+
+    def __call__(self, Xs, bs, ys):
+        if self.graphed is None:
+            from .graph import GraphedTrainStep
+            self.graphed = GraphedTrainStep(self.model, self.loss_fn, self.optimizer, Xs, bs, ys)
+        g = self.graphed
+        if Xs.shape == g.x.shape and bs.shape == g.b.shape and ys.shape == g.y.shape:
+            return g(Xs, bs, ys).clone()        # (the graph's loss buffer is overwritten by the next replay)
+        return _train_step(self.model, self.loss_fn, self.optimizer, Xs, bs, ys).detach()
+
+
 def _last_params(model):
     return (model.module if hasattr(model, "module") else model).get_last_params()
 
@@ -77,12 +95,13 @@ def _eval_loss(model, loss_fn, Xs, bs, ys, grad_norm=None):
 
 
 def train(dataloader, model: nn.Module, loss_fn, optimizer, device: str, num_loops: int = 1,
-          hide_progress_bar: bool = True, grad_norm=None) -> float:
-    """optim_helper.py:22-66"""
+          hide_progress_bar: bool = True, grad_norm=None, graph_step=None) -> float:
+    """optim_helper.py:22-66 (`graph_step`: a LazyGraphedStep to replay the step as a hipGraph)"""
     meter = AverageMeter()
     model.train()
     for Xs, bs, ys in _device_batches(dataloader, device, num_loops):
-        meter.update(_train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm).item(), n=len(Xs))
+        loss = graph_step(Xs, bs, ys) if graph_step is not None else _train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm)
+        meter.update(loss.item(), n=len(Xs))
     logger.info(f"Train error: avg loss = {meter.avg:.8f}")
     return meter.avg
 
@@ -128,13 +147,16 @@ def _epoch_mean_over_ranks(total: torch.Tensor, count: int, world_size: int) -> 
 
 
 def train_ddp(dataloader, sampler, model: nn.Module, loss_fn, optimizer, epoch: int, rank: int, world_size: int,
-              num_loops: int, grad_norm=None, reducer=None) -> float:
-    """optim_helper.py:137-183"""
+              num_loops: int, grad_norm=None, reducer=None, graph_step=None) -> float:
+    """optim_helper.py:137-183 (`graph_step`: single-GPU runs may replay the step as a hipGraph, see LazyGraphedStep)"""
     sampler.set_epoch(epoch)
     model.train()
     total, count = 0.0, 0
     for Xs, bs, ys in _device_batches(dataloader, rank, num_loops):
-        loss = _train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer)
+        if graph_step is not None:
+            loss = graph_step(Xs, bs, ys)
+        else:
+            loss = _train_step(model, loss_fn, optimizer, Xs, bs, ys, grad_norm, reducer)
         total = total + loss.detach() * len(Xs)
         count += len(Xs)
     return _epoch_mean_over_ranks(total, count, world_size)

@@ -75,3 +75,21 @@ def test_graph_requirements_are_checked(eng):
     x, b, y = (t.to(DEV) for t in synthetic_inputs(1, (16, 16, 16), 4, 3, "iid"))
     with pytest.raises(ValueError):
         eng.GraphedTrainStep(m, lf, o, x, b, y)
+
+
+def test_train_loop_with_graph_replay_equals_the_eager_loop(eng):
+    """optim_helper.train(..., graph_step=LazyGraphedStep(...)): same epoch loss and parameters as the eager loop, bit for
+    bit, including a last partial batch (which runs eagerly)"""
+    from sr3d_amd.src.optim_helper import LazyGraphedStep, train
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = cfg_of(d), sub(d, "sd")
+    full = [synthetic_inputs(2, (16, 16, 16), 4, 70 + i, "iid") for i in range(3)]
+    part = synthetic_inputs(1, (16, 16, 16), 4, 99, "iid")
+    loader = [(x, b[:, 0], y) for x, b, y in full + [part]]       # the loops add the mask's channel dimension themselves
+    m1, lf1, o1 = _setup(eng, cfg, sd, capturable=False)
+    l1 = train(loader, m1, lf1, o1, DEV)
+    m2, lf2, o2 = _setup(eng, cfg, sd, capturable=True)
+    gs = LazyGraphedStep(m2, lf2, o2)
+    l2 = train(loader, m2, lf2, o2, DEV, graph_step=gs)
+    assert l1 == l2 and gs.graphed.replays == 3
+    assert torch.equal(o1.flat_param, o2.flat_param)

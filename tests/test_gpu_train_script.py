@@ -14,7 +14,8 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_train_script_single_gpu(tmp_path):
+@pytest.mark.parametrize("variant", ["gradnorm", "hipgraph"])
+def test_train_script_single_gpu(tmp_path, variant):
     data_root = write_synthetic_tree(tmp_path / "d", HR=(16, 32, 32), days=6)
     cfg = {
         "data": {"data_dir_names": ["10"], "train_valid_test_ratios": [0.6, 0.2, 0.2], "hr_org_size": [16, 32, 32],
@@ -32,6 +33,9 @@ def test_train_script_single_gpu(tmp_path):
                   "conv_mode_feat_extraction": "g_conv_with_separated_bias",
                   "conv_mode_down_block": "g_conv_with_separated_bias", "conv_mode_up_block": None},
     }
+    if variant == "hipgraph":      # engine extension: the step as a hipGraph replay (no GradNorm: it has its own optimizer)
+        del cfg["train"]["grad_norm"]
+        cfg["train"]["hip_graph"] = True
     (tmp_path / "exp").mkdir()
     cfg_path = tmp_path / "exp" / "tiny.yml"
     cfg_path.write_text(yaml.safe_dump(cfg))
@@ -47,7 +51,7 @@ def test_train_script_single_gpu(tmp_path):
     hist = (out / "learning_history.csv").read_text().strip().splitlines()
     assert hist[0] == "loss,val_loss" and len(hist) == 3
     assert "Epoch: 2" in (out / "log.txt").read_text()
-    assert (out / "grad_norm_weights_0.csv").exists()
+    assert (out / "grad_norm_weights_0.csv").exists() == (variant == "gradnorm")
     # final evaluation: the reference's ten metrics on the whole-domain test loader, then the inferences
     log = (out / "log.txt").read_text()
     for name in ("L1", "MaskedL1", "MaskedL1NearWall", "ResidualContinuityEq", "AbsDiffTemperature", "DiffVelocityNorm",
