@@ -21,8 +21,9 @@
 //
 // One 256-thread workgroup, TWO per CU (80 KB of LDS each): 64 (or 32) output rows x 2 x 4 x 32 voxels; wave w owns
 // voxel rows 2w, 2w+1 for all row tiles.  Chunk = 16 channels = K of one MFMA.  The two workgroups of a CU are
-// independent, so the barriers and the halo refill of one are covered by the MFMAs of the other (one 512-thread
-// workgroup per CU kept the matrix pipe 60 % busy: all eight waves met at the same barriers).
+// independent, so the barriers and the halo refill of one are covered by the MFMAs of the other.  (One 512-thread
+// workgroup per CU on 4 x 4 x 32 voxels measured the same 58-60 % matrix-pipe utilisation: the kernel is bound by the
+// part's power limit; the small workgroups stayed because smaller launches still fill the chip.)
 //   halo      [part][channel half][voxel 4x6x34][8 ch] fp16 (56 KB): raw fp32 rows come in by buffer loads with
 //             hardware range checks one chunk ahead (registers), are scaled, split and written as 16-byte pieces;
 //             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
