@@ -2,6 +2,7 @@
 //   mode 0  fp32 MFMA 32x32x2 (8 per 16 k-values)
 //   mode 1  "3 x bf16": 6 bf16 MFMAs 32x32x16 per 16 k-values (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
 //   mode 2  "2 x f16":  3 f16 MFMAs 32x32x16 per 16 k-values (hi*hi, hi*lo, lo*hi) -- the scheme of csrc/sr3d_hconv.hip
+//   mode 3  the same products as 16x16x32 MFMAs (4 accumulator registers per tile, K = 32)
 // Each mode runs for tens of milliseconds with lane-dependent operands (power management reacts within milliseconds;
 // a 2 ms burst with constant operands overstates the sustained rate) and reports the shader clock it saw
 // (s_memtime cycles per s_memrealtime tick of 100 MHz).  Build and run:
@@ -12,6 +13,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* clk, int iters, float seed) {
@@ -20,6 +22,9 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  f32x4 acc4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
   // operand sets that differ per lane and per use (pseudo-random mantissas)
   float af[4], bf[4];
@@ -47,12 +52,25 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
       for (int k = 0; k < 6; k++)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[(k + i) & 3], bb[(k ^ i) & 3], acc[i], 0, 0, 0);
-    } else {
+    } else if (MODE == 2) {
 #pragma unroll
       for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(k + i) & 3], bh[(k ^ i) & 3], acc[i], 0, 0, 0);
+    } else {
+      // the same FLOPs per iteration: 4 accumulators x 32x32x16 = 16 tiles of 16x16; per tile 3 products x (K = 16 -> half
+      // an MFMA of K = 32): 24 MFMAs 16x16x32 per iteration
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc4[(2 * i + k) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[(k + i) & 3], bh[(k ^ i) & 3], acc4[(2 * i + k) & 15], 0, 0, 0);
     }
+  }
+  if (MODE == 3) {
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[i >> 2][(i & 3) * 4 + r] = acc4[i][r];
   }
   float s = 0.f;
 #pragma unroll
@@ -89,12 +107,14 @@ int main() {
   unsigned long long* clk;
   hipMalloc(&out, 256 * 2 * 256 * sizeof(float));
   hipMalloc(&clk, 512 * 2 * sizeof(unsigned long long));
-  double mhz[3], ms[3];
+  double mhz[4], ms[4];
   const double t0 = run<0>(out, clk, 40000, &mhz[0], &ms[0]);
   const double t1 = run<1>(out, clk, 100000, &mhz[1], &ms[1]);
   const double t2 = run<2>(out, clk, 200000, &mhz[2], &ms[2]);
+  const double t3 = run<3>(out, clk, 200000, &mhz[3], &ms[3]);
   printf("fp32 MFMA 32x32x2      : %7.1f TFLOP/s                         %6.1f ms at %4.0f MHz\n", t0, ms[0], mhz[0]);
   printf("3 x bf16 (6 x 32x32x16): %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t1, t1 / t0, ms[1], mhz[1]);
   printf("2 x f16  (3 x 32x32x16): %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t2, t2 / t0, ms[2], mhz[2]);
+  printf("2 x f16  (as 16x16x32) : %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t3, t3 / t0, ms[3], mhz[3]);
   return 0;
 }
