@@ -165,19 +165,24 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   // register allocator shuffled the accumulators between the two MFMA sections and spilled 436 bytes.
   auto run = [&](auto few_tag) {
   constexpr bool FEW = decltype(few_tag)::value;
-  f32x16 acc[FEW ? 3 : 2][RT];
+  // v_mfma_f32_16x16x32_f16: one MFMA reduces over the WHOLE 32-voxel row segment; the tiles are 16 rows x 16 channels
+  // (4 accumulator registers).  Same products and fragment reads as with 32x32x16, but the 16x16x32 shape is 14 % more
+  // power-efficient on this part (tools/mfma_rate.hip), and this kernel runs at the power limit.
+  constexpr int NT = 2 * RT;                  // 16-row tiles of the n block; 2 16-channel tiles of the c block
+  constexpr int NK = FEW ? 3 : 2;             // accumulator slots (see below)
+  f32x4 acc[NK][NT][2];
 #pragma unroll
-  for (int k = 0; k < (FEW ? 3 : 2); k++)
+  for (int k = 0; k < NK; k++)
 #pragma unroll
-    for (int i = 0; i < RT; i++)
+    for (int i = 0; i < NT; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[k][i][r] = 0.f;
+      for (int j = 0; j < 2; j++) acc[k][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float acc_sign = 1.f;
   // Accumulator slots.  The 27 taps are 9 (kz, ky) groups x 3 kx; 9 waves with a group each would sit 3-2-2-2 on the four
-  // SIMDs (75 % of the matrix pipes busy at best).  So: waves 0..8 own group w with kx = 0, 1 (2 * RT tiles), waves 9..11
-  // own kx = 2 of the groups 3(w-9) .. +2 (3 * RT tiles): 12 / 14 / 14 / 14 tiles per SIMD.
+  // SIMDs (75 % of the matrix pipes busy at best).  So: waves 0..8 own group w with kx = 0, 1, waves 9..11 own kx = 2 of
+  // the groups 3(w-9) .. +2: 12 / 14 / 14 / 14 units per SIMD.
   const int g0 = FEW ? 3 * (wave - 9) : wave;
-  const int fr = (lane & 31) * PITCH + (lane >> 5) * 16;
+  const int fr = (lane & 15) * PITCH + (lane >> 4) * 16;   // fragment: row / channel lane & 15, voxels 8 (lane >> 4) .. +8
   auto xrow = [&](const int g, const int t) { return Xs + ((g / 3) * 4 + ((t + (g % 3) - 1) & 3)) * XROW + fr; };
 
   // ---- rows of this split
@@ -205,67 +210,36 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
         if (sgn != acc_sign) {   // (wave-uniform) sign alternation, see the header
 #pragma unroll
-          for (int k = 0; k < (FEW ? 3 : 2); k++)
+          for (int k = 0; k < NK; k++)
 #pragma unroll
-            for (int i = 0; i < RT; i++)
+            for (int i = 0; i < NT; i++)
 #pragma unroll
-              for (int r = 0; r < 16; r++) acc[k][i][r] = -acc[k][i][r];
+              for (int j = 0; j < 2; j++) acc[k][i][j] = -acc[k][i][j];
           acc_sign = sgn;
         }
         const unsigned char* db = Ds + (t & 1) * G::DROW + fr;
-        if constexpr (!FEW) {
-          // one X row, the dY copies of kx = 0, 1: 2 K-steps x 2 copies x RT row tiles products; the A pair of
-          // product j+1 is read before the MFMAs of product j are issued
-          const unsigned char* xb = xrow(g0, t);
-          constexpr int NP = 4 * RT;
-          h8 fa[2][2], fb[2][2];   // [buffer][hi | lo]
-          auto load_a = [&](const int j, const int buf) {
-            const int ks = j / (2 * RT), k = (j / RT) % 2, i = j % RT;
-            const unsigned char* a = db + k * G::DCOPY + i * 32 * PITCH + ks * 32;
-            fa[buf][0] = *reinterpret_cast<const h8*>(a);
-            fa[buf][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
-          };
-          auto load_b = [&](const int ks) {
-            fb[ks][0] = *reinterpret_cast<const h8*>(xb + ks * 32);
-            fb[ks][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
-          };
-          load_b(0);
-          load_a(0, 0);
-          load_b(1);
+        // slot k: (X row, dY copy) = (group g0, copy k) for waves 0..8, (group g0 + k, copy 2) for waves 9..11
 #pragma unroll
-          for (int j = 0; j < NP; j++) {
-            if (j + 1 < NP) load_a(j + 1, (j + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const int ks = j / (2 * RT), k = (j / RT) % 2, i = j % RT;
-            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][1], acc[k][i], 0, 0, 0);
-            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][1], fb[ks][0], acc[k][i], 0, 0, 0);
-            acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][0], fb[ks][0], acc[k][i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < NK; k++) {
+          const unsigned char* xb = xrow(FEW ? g0 + k : g0, t);
+          h8 bq[2][2];   // [channel tile][hi | lo]
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            bq[j][0] = *reinterpret_cast<const h8*>(xb + j * 16 * PITCH);
+            bq[j][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + j * 16 * PITCH);
           }
-        } else {
-          // three X rows, the dY copy of kx = 2 (shared by the three)
+          const unsigned char* da = db + (FEW ? 2 : k) * G::DCOPY;
 #pragma unroll
-          for (int ks = 0; ks < 2; ks++) {
-            h8 fa[RT][2];
+          for (int i = 0; i < NT; i++) {
+            const h8 ah = *reinterpret_cast<const h8*>(da + i * 16 * PITCH), al = *reinterpret_cast<const h8*>(da + 32 * RT * PITCH + i * 16 * PITCH);
 #pragma unroll
-            for (int i = 0; i < RT; i++) {
-              const unsigned char* a = db + 2 * G::DCOPY + i * 32 * PITCH + ks * 32;
-              fa[i][0] = *reinterpret_cast<const h8*>(a);
-              fa[i][1] = *reinterpret_cast<const h8*>(a + 32 * RT * PITCH);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {   // (one B pair at a time: the wave has 170 registers)
-              const unsigned char* xb = xrow(g0 + k, t);
-              const h8 bh = *reinterpret_cast<const h8*>(xb + ks * 32), bl = *reinterpret_cast<const h8*>(xb + 32 * PITCH + ks * 32);
-#pragma unroll
-              for (int i = 0; i < RT; i++) {
-                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], bl, acc[k][i], 0, 0, 0);
-                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], bh, acc[k][i], 0, 0, 0);
-                acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], bh, acc[k][i], 0, 0, 0);
-              }
-              __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; j++) {
+              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][1], acc[k][i][j], 0, 0, 0);
+              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[j][0], acc[k][i][j], 0, 0, 0);
+              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][0], acc[k][i][j], 0, 0, 0);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // (not __syncthreads(): that would drain vmcnt and expose the latency of the loads issued above in every step;
@@ -276,21 +250,21 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     r0 = plane * p.Y + yb;
   }
 
-  // ---- partial block -> slab[split, segment][tap][n][c]
-  {
-    const int c = cb * 32 + (lane & 31);
+  // ---- partial block -> slab[split, segment][tap][n][c]; 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-    for (int k = 0; k < (FEW ? 3 : 2); k++) {
-      const int tap = FEW ? (g0 + k) * 3 + 2 : g0 * 3 + k;
-      float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
+  for (int k = 0; k < NK; k++) {
+    const int tap = FEW ? (g0 + k) * 3 + 2 : g0 * 3 + k;
+    float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
 #pragma unroll
-      for (int i = 0; i < RT; i++)
+    for (int i = 0; i < NT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int n = nb * (32 * RT) + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-          out[(long long)n * p.Cpad + c] = acc[k][i][r] * acc_sign;
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int n = nb * (32 * RT) + i * 16 + 4 * (lane >> 4) + r;
+          const int c = cb * 32 + j * 16 + (lane & 15);
+          out[(long long)n * p.Cpad + c] = acc[k][i][j][r] * acc_sign;
         }
-    }
   }
   };
   if (wave >= 9)
