@@ -27,8 +27,9 @@
 //   halo      [part][channel half][voxel 4x6x34][8 ch] fp16 (56 KB): raw fp32 rows come in by buffer loads with
 //             hardware range checks one chunk ahead (registers), are scaled, split and written as 16-byte pieces;
 //             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
-//   weights   split + packed once per call: [row block][chunk][kz][ky][kx][part][row tile][64 lanes][8 ch]; one
-//             (kz, ky) phase (3 taps, 12 KB) arrives by LDS-DMA while the previous one is multiplied (two buffers)
+//   weights   split + packed once per call: [row block][chunk][tap pair 14][part][16-row tile][64 lanes][8 ch] (a lane of
+//             the 16x16x32 A operand: row, K group = tap of the pair x channel half); one pair (8 KB) arrives by LDS-DMA
+//             while the previous one is multiplied (two buffers)
 #include "sr3d_split_f16.h"
 
 #include <limits.h>
@@ -50,10 +51,10 @@ constexpr int HVP = 2 * HNR * 64;              // voxels per plane, padded (896)
 constexpr int HPLANE = HVP * 16;               // bytes of one (part, channel half) plane
 constexpr int HBYTES = 4 * HPLANE;             // 57344
 constexpr int HNT = 256;
-constexpr int HPH = 9;                         // weight phases per chunk: (kz, ky), 3 taps each
+constexpr int HPH = 14;                        // weight phases per chunk: tap pairs (2p, 2p + 1); tap 27 is a zero dummy
 template <int RT>
 struct HGeo {
-  static constexpr int PIECES = 3 * 2 * RT;    // 1 KB fragments of one phase
+  static constexpr int PIECES = 2 * 2 * RT;    // 1 KB fragments of one phase: [hi | lo][16-row tile]
   static constexpr int WPHASE = PIECES * 1024;
   static constexpr size_t LDS = HBYTES + 2 * (size_t)WPHASE;
 };
@@ -203,21 +204,24 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     }
   };
 
-  f32x16 acc[RT][2];
+  // v_mfma_f32_16x16x32_f16 (14 % more power-efficient than 32x32x16 on this part, tools/mfma_rate.hip): K = 32 = the 16
+  // channels of the chunk at TWO taps.  Lane l of an operand: row / voxel l & 15, K group l >> 4 = 2 * (tap of the pair)
+  // + (channel half).  The wave's tile is 32 * RT rows x 2 voxel rows x 32 x = (2 RT) x 4 tiles of 16 x 16.
+  constexpr int NRT = 2 * RT;
+  f32x4 acc[NRT][4];
 #pragma unroll
-  for (int i = 0; i < RT; i++)
+  for (int i = 0; i < NRT; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // B fragment bases: voxel row vt = 2 * wave + j -> (z, y) = (vt >> 2, vt & 3)
-  int bbase[2];
+  // B fragment bases: voxel tile j = (voxel row 2 * wave + (j >> 1), x half j & 1)
+  int bbase[4];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int vt = 2 * wave + j;
-    bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
+  for (int j = 0; j < 4; j++) {
+    const int vt = 2 * wave + (j >> 1);
+    bbase[j] = ((lane >> 4) & 1) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (j & 1) * 16 + (lane & 15)) * 16;
   }
+  const bool tap_b = lane >= 32;   // this lane supplies the second tap of a pair
   const int abase = lane * 16;
 
   // ---- prologue
@@ -234,30 +238,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   __builtin_amdgcn_s_barrier();
   int s_next = s_run;
 
-  // fragments are double-buffered in registers: the reads of tap t+1 are issued before the MFMAs of tap t
-  h8 fa[2][2][RT], fb[2][2][2];   // [set][part][row tile], [set][part][voxel row]
-  // (issued in two groups of 4: more than 15 LDS reads in flight overflow the lgkmcnt counter and the compiler then
-  // waits for all of them)
-  auto frags_a = [&](const int set, const unsigned char* W, const int kx) {
-#pragma unroll
-    for (int part = 0; part < 2; part++)
-#pragma unroll
-      for (int i = 0; i < RT; i++) fa[set][part][i] = *reinterpret_cast<const h8*>(W + ((kx * 2 + part) * RT + i) * 1024);
-  };
-  auto frags_b = [&](const int set, const unsigned char* Hk, const int kx) {
-#pragma unroll
-    for (int part = 0; part < 2; part++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) fb[set][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + kx * 16);
-  };
-  auto mfmas = [&](const int set, const int i) {   // row tile i
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][1][j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][1][i], fb[set][0][j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][j], acc[i][j], 0, 0, 0);
-    }
-  };
+  // halo byte offset of tap t = (kz, ky, kx); the dummy tap 27 reads where tap 26 does (its weights are zero)
+  auto tap_off = [](const int t) { const int u = t > 26 ? 26 : t; return (((u / 9) * HHY + (u / 3) % 3) * HHX + u % 3) * 16; };
   int phase = 0;
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
 #pragma unroll   // (rolled, the next chunk's raw rows and their split form are both live in every phase: spills)
@@ -276,18 +258,30 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       if (HCONV_ABL != 2 && phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
       if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
-      const unsigned char* Hk = Hs + ((kzy / 3) * HHY + (kzy % 3)) * (HHX * 16);
-      frags_a(0, W, 0);
-      frags_b(0, Hk, 0);
+      // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
+      const unsigned char* Hk = Hs + (tap_b ? tap_off(2 * kzy + 1) : tap_off(2 * kzy));
+      h8 fb[2][4], fa[2][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
 #pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        if (HCONV_ABL != 4 && kx + 1 < 3) frags_a((kx + 1) & 1, W, kx + 1);
+      for (int part = 0; part < 2; part++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
+      // row tiles two at a time (12 LDS reads in flight at most: 16 overflow the lgkmcnt counter model)
+#pragma unroll
+      for (int ih = 0; ih < NRT; ih += 2) {
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+            if (HCONV_ABL != 4 || (kzy == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(HCONV_ABL == 4 ? 0 : (kx & 1), 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (HCONV_ABL != 4 && kx + 1 < 3) frags_b((kx + 1) & 1, Hk, kx + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (RT == 2) mfmas(HCONV_ABL == 4 ? 0 : (kx & 1), 1);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[1][j], acc[ih + i][j], 0, 0, 0);
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
       // the next phase's weights (issued above, BEFORE the raw rows) have landed; in phase 0 the 8 * HNR raw-row
@@ -307,11 +301,9 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       // moves the accumulators to the next chunk's scale when that chunk is larger than everything before it.)
       const float flip = -ldexpf(1.f, s_next - s_run);
 #pragma unroll
-      for (int i = 0; i < RT; i++)
+      for (int i = 0; i < NRT; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+        for (int j = 0; j < 4; j++) acc[i][j] *= flip;
       s_run = s_next;
       write_halo();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -319,52 +311,53 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     }
   }
 
-  // ------------------------------------------------------------------ epilogue (direct 32 x 32 layout)
+  // ------------------------------------------------------------------ epilogue (16 x 16 tiles: column = lane & 15 = voxel,
+  // row = 4 (lane >> 4) + register)
   // (sign: the accumulators changed sign nchunks - 1 times)
   const float out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
-  const int ox = x0 + (lane & 31);
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
-  if (ox >= p.X) return;
+  const int rlane = 4 * (lane >> 4);
   if (p.epi == SR3D_EPI_GATED) {
-    if constexpr (RT == 2) {
-      const int cbase = rblock / 2 + 4 * (lane >> 5);
+    if constexpr (RT == 2) {   // rows 0..31 of the block: features, 32..63: gates of the same 32 channels
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int vt = 2 * wave + j;
-        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-        if (oz >= p.Z || oy >= p.Y) continue;
+      for (int j = 0; j < 4; j++) {
+        const int vt = 2 * wave + (j >> 1);
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
+        if (oz >= p.Z || oy >= p.Y || ox >= p.X) continue;
         const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int co = cbase + (r & 3) + 8 * (r >> 2);
-          if (co < p.Cg) {
-            float f = acc[0][j][r] * out_mult;
-            if (p.bias) f += p.bias[co];
-            const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
-            const float s = 1.f / (1.f + expf(-g));
-            f = split_act(f, p.act);
-            const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
-            p.y[o] = s * f;
-            if (p.save_f) {
-              p.save_f[o] = f;
-              p.save_s[o] = s;
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int co = rblock / 2 + i * 16 + rlane + r;
+            if (co < p.Cg) {
+              float f = acc[i][j][r] * out_mult;
+              if (p.bias) f += p.bias[co];
+              const float g = acc[2 + i][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
+              const float sg = 1.f / (1.f + expf(-g));
+              f = split_act(f, p.act);
+              const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+              p.y[o] = sg * f;
+              if (p.save_f) {
+                p.save_f[o] = f;
+                p.save_s[o] = sg;
+              }
             }
           }
-        }
       }
     }
   } else if (p.epi == SR3D_EPI_UNSHUFFLE) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int vt = 2 * wave + j;
-      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-      if (oz >= p.Z || oy >= p.Y) continue;
+    for (int j = 0; j < 4; j++) {
+      const int vt = 2 * wave + (j >> 1);
+      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
+      if (oz >= p.Z || oy >= p.Y || ox >= p.X) continue;
 #pragma unroll
-      for (int i = 0; i < RT; i++)
+      for (int i = 0; i < NRT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < 4; r++) {
+          const int n = rblock + i * 16 + rlane + r;
           if (n < p.N) {
             const float val = split_act(acc[i][j][r] * out_mult + p.bias[n], p.act);
             const int f = n / p.unsh_C, c = n - f * p.unsh_C;
@@ -376,10 +369,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < RT; i++)
+    for (int i = 0; i < NRT; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+      for (int r = 0; r < 4; r++) {
+        const int n = rblock + i * 16 + rlane + r;
         if (n >= p.N) continue;
         const int si = cat_find(p.out, n);
         float* base = cat_ptr(p.out, si);
@@ -387,10 +380,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const int vt = 2 * wave + j;
-          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-          if (oz < p.Z && oy < p.Y) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = split_act(acc[i][j][r] * out_mult + bv, p.act);
+        for (int j = 0; j < 4; j++) {
+          const int vt = 2 * wave + (j >> 1);
+          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
+          if (oz < p.Z && oy < p.Y && ox < p.X) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = split_act(acc[i][j][r] * out_mult + bv, p.act);
         }
       }
   }
@@ -426,36 +419,39 @@ struct HPackParams {
 __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
   const int sw = split_scale_exp(*p.absmax_w);
   const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
-  const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;   // items of 8 channels
+  // items of 8 channels: (row block, chunk, 16-row tile, channel half, row, tap 0..27); tap 27 is the zero dummy
+  const long long total = (long long)p.nblk * p.nchunks * 28 * p.RT * 64;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     // the tap runs fastest over the threads: the 27 taps of one (row, channel) are contiguous in the weight tensor, so a
     // wave's reads are 108-byte runs (with the row fastest every lane read its own 108-byte segment: 4.5 ms per step)
     long long r = e;
-    const int tap = r % 27;
-    r /= 27;
-    const int row = r % 32;
-    r /= 32;
+    const int tap = r % 28;
+    r /= 28;
+    const int row = r % 16;
+    r /= 16;
     const int h = r % 2;
     r /= 2;
-    const int rt = r % p.RT;
-    r /= p.RT;
+    const int rt = r % (2 * p.RT);          // 16-row tile inside the block
+    r /= 2 * p.RT;
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
-    const int n = p.n_off + nb * (32 * p.RT) + rt * 32 + row;
+    const int n = p.n_off + nb * (32 * p.RT) + rt * 16 + row;
     const float* w = nullptr;   // -> w[.][k = 0][tap 0]; element (k, tap) at w[k * kstride + tapidx]
     long long kstride = 27;
     int tapidx = tap;
-    if (p.kind == SR3D_PACK_FWD) {
-      if (n < p.N) w = p.w1 + (long long)n * p.Cin * 27;
-    } else if (p.kind == SR3D_PACK_FWD_GATED) {
-      const int co = (n >> 6) * 32 + (n & 31);   // 64-row block = 32 feature rows, then the 32 gate rows
-      if (co < p.Cout) w = ((n & 32) ? p.w2 : p.w1) + (long long)co * p.Cin * 27;
-    } else if (n < p.N) {   // input gradient: rows = input channels that need a gradient, K = output channels, taps mirrored
-      const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
-      const int ci = p.cbeg[si] + (n - p.rbeg[si]);
-      w = p.w1 + (long long)ci * 27;
-      kstride = (long long)p.Cin * 27;
-      tapidx = 26 - tap;
+    if (tap < 27) {
+      if (p.kind == SR3D_PACK_FWD) {
+        if (n < p.N) w = p.w1 + (long long)n * p.Cin * 27;
+      } else if (p.kind == SR3D_PACK_FWD_GATED) {
+        const int co = (n >> 6) * 32 + (n & 31);   // 64-row block = 32 feature rows, then the 32 gate rows
+        if (co < p.Cout) w = ((n & 32) ? p.w2 : p.w1) + (long long)co * p.Cin * 27;
+      } else if (n < p.N) {   // input gradient: rows = input channels that need a gradient, K = output channels, taps mirrored
+        const int si = (n >= p.rbeg[1]) + (n >= p.rbeg[2]) + (n >= p.rbeg[3]);
+        const int ci = p.cbeg[si] + (n - p.rbeg[si]);
+        w = p.w1 + (long long)ci * 27;
+        kstride = (long long)p.Cin * 27;
+        tapidx = 26 - tap;
+      }
     }
     h8 hi, lo;
 #pragma unroll
@@ -475,10 +471,12 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
     }
-    const long long piece0 = ((((long long)nb * p.nchunks + chunk) * 27 + tap) * 2 + 0) * p.RT + rt;
-    const long long piece1 = piece0 + p.RT;
-    *reinterpret_cast<h8*>(p.img + piece0 * 512 + (h * 32 + row) * 8) = hi;
-    *reinterpret_cast<h8*>(p.img + piece1 * 512 + (h * 32 + row) * 8) = lo;
+    // fragment of (pair = tap / 2, part, tile): lane = row + 16 * (2 * (tap & 1) + h)  [MFMA K group = tap of the pair, half]
+    const long long frag0 = ((((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * 2 + 0) * (2 * p.RT) + rt;
+    const long long frag1 = frag0 + 2 * p.RT;
+    const int l = row + 16 * (2 * (tap & 1) + h);
+    *reinterpret_cast<h8*>(p.img + frag0 * 512 + l * 8) = hi;
+    *reinterpret_cast<h8*>(p.img + frag1 * 512 + l * 8) = lo;
   }
 }
 
@@ -540,7 +538,7 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
     p.RT = region == 0 ? 2 : 1;
     p.n_off = region == 0 ? 0 : n2 * 64;
     p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * HPH * (HGeo<2>::WPHASE / 2));
-    const long long total = (long long)p.nblk * p.nchunks * 27 * p.RT * 64;
+    const long long total = (long long)p.nblk * p.nchunks * 28 * p.RT * 64;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(hconv_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
     SR3D_HIP(hipGetLastError());
