@@ -1,12 +1,12 @@
 // Stride-1 3x3x3 convolution (forward and input gradient) with fp32 operands split into two fp16 halves, on
-// v_mfma_f32_32x32x16_f16.  Default for the layers that fill the chip (use_hconv in sr3d_igemm.hip); SR3D_SPLIT_F16=0
+// v_mfma_f32_16x16x32_f16.  Default for the layers that fill the chip (use_hconv in sr3d_igemm.hip); SR3D_SPLIT_F16=0
 // puts every stride-1 layer back on the fp32 Winograd kernel, =2 forces this kernel for every eligible layer.
 //
 // Why: gfx950's fp32 MFMA runs at 1/16 of the f16 rate.  An fp32 value scaled into [2^13, 2^14) splits EXACTLY into
 // hi = fp16(a) and lo = fp16(a - hi) with |a - hi - lo| <= 2^-22 |a|, and
 //        a * b  =  hi_a hi_b + hi_a lo_b + lo_a hi_b  (+ lo_a lo_b ~ 2^-22 |a b|, dropped)
-// accumulated in the MFMA's fp32 accumulator: three f16 MFMAs (K = 16 each, 32 cycles) replace eight fp32 MFMAs
-// (K = 2, 64 cycles), 5.3x less matrix-pipe time per product at a per-product error of ~2^-21, the size of fp32's own
+// accumulated in the MFMA's fp32 accumulator: three f16 MFMAs (32x32 x K = 16 in 32 cycles, or two 16x16 x K = 32 in 16
+// cycles each) replace eight fp32 MFMAs (K = 2, 64 cycles), 5.3x less matrix-pipe time per product at a per-product error of ~2^-21, the size of fp32's own
 // rounding in a 27 K-term sum.  The Winograd form of this does not fit the CU (K = 16 channels of V for 5 planes x
 // 16 points x 32 tiles are 164 KB of LDS), so this is a DIRECT implicit GEMM: 81 f16 MFMAs per (32 rows x 32 voxels
 // x 16 channels) = 2592 cycles, against 6144 for fp32 Winograd.

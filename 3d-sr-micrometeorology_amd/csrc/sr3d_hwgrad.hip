@@ -1,10 +1,10 @@
 // Weight gradient of the stride-1 3x3x3 convolutions on the split-f16 scheme of sr3d_hconv.hip (fp32 operands as two
-// fp16 halves, three v_mfma_f32_32x32x16_f16 per product group, fp32 accumulate):
+// fp16 halves, three v_mfma_f32_16x16x32_f16 per product group, fp32 accumulate):
 //
 //   dW[n][c][kz,ky,kx] = sum_{b,z,y,x'} dY[n][z][y][x' - kx + 1] * X[c][z + kz - 1][y + ky - 1][x']
 //
-// One MFMA reduces over K = 16 consecutive x' of one row: A = a dY row segment (rows n), B = an X row segment (columns
-// c).  The tap shifts in z and y pick WHICH X row a wave reads; the shift in x would make one operand start one
+// One MFMA reduces over the K = 32 consecutive x' of a row segment: A = a dY row segment (16 rows n), B = an X row
+// segment (16 columns c).  The tap shifts in z and y pick WHICH X row a wave reads; the shift in x would make one operand start one
 // element off a 16-byte boundary -- so the smaller operand (dY) is staged three times, shifted by -1, 0, +1, and every
 // fragment is one aligned ds_read_b128.
 //
