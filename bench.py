@@ -38,9 +38,10 @@ import torch.distributed as dist  # noqa: E402
 FLOP_PER_VOXEL = 8_486_693
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_f16: 32 cycles per SIMD)
-# what tools/mfma_rate.hip sustains for 100 ms with register operands only: the f16 MFMA loop runs into the power limit
-# and the shader clock settles at 1.645 GHz (fp32 MFMA: 152 TFLOP/s at 2.33 GHz)
-F16_MFMA_SUSTAINED_TFLOPS = 1651.0
+# what tools/mfma_rate.hip sustains for 100 ms with register operands only: the f16 MFMA loop runs into the power limit.
+# v_mfma_f32_16x16x32_f16 (the shape hconv_kernel uses): 3 x 634.6 TFLOP/s at 1.89 GHz; 32x32x16: 3 x 558 at 1.70 GHz
+# (fp32 MFMA: 152 TFLOP/s at 2.33 GHz, not throttled)
+F16_MFMA_SUSTAINED_TFLOPS = 1904.0
 # HBM traffic of the dominant kernel family per launch, from separate rocprofv3 --pmc passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass; FETCH_SIZE doubled as the guide prescribes for gfx950)
 TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")]
@@ -308,8 +309,9 @@ def main():
             note = ("achieved = f16 MFMA FLOPs the kernel EXECUTES per second = 3 x algorithmic FLOPs of the 3x3x3 "
                     "convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d); channel padding to 16 not counted) / kernel "
                     "time from HIP events; peak = dense f16 MFMA at 2.4 GHz.  The f16 MFMA is POWER-bound on this part: "
-                    f"tools/mfma_rate.hip sustains {F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s (register operands only, 100 ms, "
-                    "clock settling at 1.645 GHz) -- frac_of_sustained is against that")
+                    f"tools/mfma_rate.hip sustains {F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s with the kernel's MFMA shape, 16x16x32 "
+                    "(register operands only, 100 ms, clock settling at 1.89 GHz; 1674 with 32x32x16) -- frac_of_sustained is "
+                    "against that")
         else:
             kernel_desc = ("stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
                            "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)")
