@@ -166,6 +166,30 @@ struct SrProfScope {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// One-time launch setup that is a property of the DEVICE (hipFuncSetAttribute: dynamic LDS above 64 KB), keyed on the
+// current device: a process may run the engine on cuda:1 after cuda:0 from the same thread.
+#include <atomic>
+#include <mutex>
+class SrPerDevice {
+ public:
+  template <typename F>
+  int once(F&& setup) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_.load(std::memory_order_acquire) & bit) return SR3D_OK;
+    std::lock_guard<std::mutex> lk(mu_);
+    if (done_.load(std::memory_order_relaxed) & bit) return SR3D_OK;
+    if (int rc = setup()) return rc;
+    done_.fetch_or(bit, std::memory_order_release);
+    return SR3D_OK;
+  }
+
+ private:
+  std::mutex mu_;
+  std::atomic<unsigned long long> done_{0};
+};
+
 int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channels, ChanCat* out, const char* what);
 
 __device__ __forceinline__ int cat_find(const ChanCat& c, int ch) {

@@ -557,12 +557,13 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st
   row_split(p.N, &n2, &n1);
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
-  static thread_local bool configured = false;
-  if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2>::LDS));
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1>::LDS));
-    configured = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1>::LDS));
+        return SR3D_OK;
+      }))
+    return rc;
   void* tok = nullptr;
   if (sr3d_prof_active()) {
     const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;

@@ -497,14 +497,15 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
   p.nchunks = ceil_div(p.K, HKC);
   int n2, n1;
   row_split(p.N, &n2, &n1);
-  static thread_local bool configured = false;
-  if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
-    configured = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
+        return SR3D_OK;
+      }))
+    return rc;
   int gz, gy, gx;   // tile space of the launch (mode 2: class 0 = even positions, the largest)
   if (mode == 1) {
     gz = p.Z, gy = p.Y, gx = p.X;

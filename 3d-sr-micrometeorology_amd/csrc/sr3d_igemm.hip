@@ -602,10 +602,16 @@ int launch_one(IgemmParams& p, int B, int nblk, hipStream_t st) {
   p.ntz = ceil_div(p.OZ, TZ), p.nty = ceil_div(p.OY, TY), p.ntx = ceil_div(p.OX, 32);
   auto kern = igemm_kernel<S_IN, LO, HI, TZ, TY, RT, KC>;
   const size_t lds = C::lds_bytes(p.ncls > 0 ? 8 : p.ntaps);
-  static thread_local size_t configured = 0;
-  if (lds > configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
+  {   // the attribute is per device; this instantiation is launched with several LDS sizes: keep the largest per device
+    static std::mutex mu;
+    static size_t configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (lds > configured[dev & 63]) {
+      SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[dev & 63] = lds;
+    }
   }
   p.grid_nblk = nblk;
   SR3D_CHECK((long long)p.ntz * p.nty * p.ntx * nblk < (1ll << 31) && B <= 65535, SR3D_E_ARG, "igemm: grid too large");

@@ -672,11 +672,12 @@ template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_>
 int launch_wgrad_v(const WgradParams& p, dim3 grid, hipStream_t st) {
   auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC, CTW_>;
   constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N, CTW_>::lds_bytes;
-  static thread_local bool cfg = false;
-  if (!cfg) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    cfg = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        return SR3D_OK;
+      }))
+    return rc;
   hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

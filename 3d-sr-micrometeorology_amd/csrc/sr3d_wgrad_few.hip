@@ -201,11 +201,12 @@ FewPlan few_plan(const sr3d_conv_desc_t* d, int M, int few_n) {
 template <int F>
 int launch_few(const FewParams& p, const FewPlan& pl, hipStream_t st) {
   constexpr int kLds = (F * FHC + 64 * F * 27) * 4;
-  static thread_local bool cfg = false;
-  if (!cfg) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wgrad_few_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    cfg = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)wgrad_few_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        return SR3D_OK;
+      }))
+    return rc;
   hipLaunchKernelGGL(wgrad_few_kernel<F>, dim3(pl.S, pl.mblk), dim3(256), kLds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

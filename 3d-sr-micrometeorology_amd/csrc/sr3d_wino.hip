@@ -518,14 +518,15 @@ int sr3d_wino_launch(SrWinoParams& p, int B, hipStream_t st) {
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31) && B <= 65535, SR3D_E_ARG, "winograd conv: grid too large");
   SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "winograd conv: more than 2^29 voxels per channel");
   SR3D_CHECK(p.K <= WCT, SR3D_E_ARG, "winograd conv: more than %d input channels", WCT);
-  static thread_local bool configured = false;
-  if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-    configured = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        return SR3D_OK;
+      }))
+    return rc;
   void* tok = nullptr;
   if (sr3d_prof_active()) {
     const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;

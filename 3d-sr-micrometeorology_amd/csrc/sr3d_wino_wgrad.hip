@@ -477,12 +477,13 @@ int sr3d_wino_wgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
   p.nty = g.nty, p.ntx = g.ntx, p.ntiles = g.ntiles, p.per_split = g.per_split;
   p.slab = ws, p.Npad = g.Npad, p.Cpad = g.Cpad;
   SR3D_CHECK(g.cblk <= 65535 && g.nblk <= 65535, SR3D_E_ARG, "winograd wgrad: too many blocks");
-  static thread_local bool configured = false;
-  if (!configured) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
-    SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
-    configured = true;
-  }
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
+        SR3D_HIP(hipFuncSetAttribute((const void*)wino_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGLds));
+        return SR3D_OK;
+      }))
+    return rc;
   void* tok = nullptr;
   if (sr3d_prof_active())
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st, &tok);

@@ -98,7 +98,7 @@ class DatasetWithoutAligningResolution(Dataset):
     def __getitem__(self, idx: int):
         lr_c, bldg, hr_c = self._raw_crops(idx)
         if self.raw:      # normalisation happens on the GPU (src/device_pipeline.py)
-            return lr_c.contiguous(), bldg.contiguous(), hr_c.contiguous()
+            return lr_c.contiguous(), torch.nan_to_num(bldg, nan=self.nan_value).contiguous(), hr_c.contiguous()
         if self.lr_scaling is not None:
             lr_c = self.lr_scaling * lr_c
         hr_c = torch.nan_to_num(self._normalise(hr_c, self.use_clipping), nan=self.nan_value)

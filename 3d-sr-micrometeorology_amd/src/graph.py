@@ -13,6 +13,7 @@ from typing import Callable
 
 import torch
 
+from .. import ops
 from .optim import FlatAdam
 
 
@@ -39,7 +40,10 @@ class GraphedTrainStep:
             for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev), keep):
                 dst.copy_(src)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the capture happens on the first batch INSIDE the training loop, while the DataLoader's pin-memory
+        # thread may be calling hipHostMalloc / hipEventQuery for the batches it prefetches; in the default "global" mode
+        # such a call from another thread invalidates the capture.  Only this thread's calls are part of the graph.
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._body()
         self.replays = 0
 
@@ -60,5 +64,6 @@ class GraphedTrainStep:
         self.b.copy_(bs, non_blocking=True)
         self.y.copy_(ys, non_blocking=True)
         self.graph.replay()
+        ops.invalidate_eval_cache()     # the replay rewrote buffers the metrics cache may have seen
         self.replays += 1
         return self.loss

@@ -53,8 +53,7 @@ def calc_mask_near_build_wall(building: torch.Tensor, num_filter_applications: i
 
 class MyL1Loss(nn.Module):
     def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor = None):
-        if masks is not None and not (torch.is_grad_enabled() and predicts.requires_grad) and predicts.dim() == 5 \
-                and predicts.shape[1] == 4:
+        if not (torch.is_grad_enabled() and predicts.requires_grad) and ops.eval_shapes_ok(predicts, targets, masks):
             # evaluation: the value comes out of the fused metrics pass (shared with the other metrics of the batch)
             return ops.eval_metrics(predicts, targets, masks, (None,) * 4)[0]
         return ops.L1LossFn.apply(predicts, targets)
@@ -108,7 +107,15 @@ class WeightedL1Loss(nn.Module):
         self.weight = weight_outside_building
 
     def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
-        return ops.WeightedLpFn.apply(predicts, targets, masks, float(self.weight), self.power)
+        if ops.eval_shapes_ok(predicts, targets, masks):
+            return ops.WeightedLpFn.apply(predicts, targets, masks, float(self.weight), self.power)
+        # any other broadcastable shape (the reference accepts them, loss_maker.py:222-232): the plain expressions
+        e = (predicts - targets).abs() if self.power == 1 else (predicts - targets) ** 2
+        inside = torch.broadcast_to(masks, e.shape)
+        n_in = inside.sum()
+        n_out = e.numel() - n_in
+        s_in = (e * inside).sum()
+        return (self.weight * s_in / (n_in + 1.0) + (e.sum() - s_in) / (n_out + 1.0)) / (self.weight + 1.0)
 
 
 class WeightedL2Loss(WeightedL1Loss):

@@ -50,13 +50,28 @@ class LazyGraphedStep:
 
     def __init__(self, model, loss_fn, optimizer):
         self.model, self.loss_fn, self.optimizer, self.graphed = model, loss_fn, optimizer, None
+        self.failed = False     # the capture raised once: every step runs eagerly from then on
+
+    def _capture(self, Xs, bs, ys):
+        from .graph import GraphedTrainStep
+        opt = self.optimizer
+        keep = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev)]
+        try:
+            self.graphed = GraphedTrainStep(self.model, self.loss_fn, opt, Xs, bs, ys)
+        except Exception as e:   # a capture-unsafe call somewhere (another library, another thread): train eagerly
+            logger.warning(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                           "continuing with eager steps")
+            torch.cuda.synchronize()
+            with torch.no_grad():   # the warm-up / aborted capture must leave no trace in the optimizer state
+                for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev), keep):
+                    dst.copy_(src)
+            self.failed = True
 
     def __call__(self, Xs, bs, ys):
-        if self.graphed is None:
-            from .graph import GraphedTrainStep
-            self.graphed = GraphedTrainStep(self.model, self.loss_fn, self.optimizer, Xs, bs, ys)
+        if self.graphed is None and not self.failed:
+            self._capture(Xs, bs, ys)
         g = self.graphed
-        if Xs.shape == g.x.shape and bs.shape == g.b.shape and ys.shape == g.y.shape:
+        if g is not None and Xs.shape == g.x.shape and bs.shape == g.b.shape and ys.shape == g.y.shape:
             return g(Xs, bs, ys).clone()        # (the graph's loss buffer is overwritten by the next replay)
         return _train_step(self.model, self.loss_fn, self.optimizer, Xs, bs, ys).detach()
 

@@ -103,10 +103,13 @@ def cpu_baseline(cfg, budget_s=20.0):
     from oracle import ref_cpu as R
     cores = host_cores()
     torch.set_num_threads(cores)
-    hr = (32, 64, 64)
+    # BASELINE.json configs[0]: a single 32x32x16 LR volume -> 2x (num_x2upsample = 1), i.e. HR 32x64x64
+    cfg = json.loads(json.dumps(cfg))
+    cfg["model"]["num_x2upsample"] = 1
+    hr, scale = (32, 64, 64), 2
     sd = R.random_state_dict(cfg["model"], seed=42)
     opt = R.AdamState(sd, lr=cfg["train"]["lr"])
-    x, b, y = synthetic_batch(1, hr, 4, 1234, "cpu")
+    x, b, y = synthetic_batch(1, hr, scale, 1234, "cpu")
     R.train_step(sd, opt, cfg, x, b, y)  # warm-up (first call pays oneDNN primitive creation)
     times = []
     t_all = time.time()
@@ -120,7 +123,8 @@ def cpu_baseline(cfg, budget_s=20.0):
     vox = hr[0] * hr[1] * hr[2]
     return {"value": vox / sec, "unit": "HR voxels/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{len(times)} full training steps (fwd+loss+bwd+Adam, same model and loss) of the CPU oracle "
-                      f"on one HR {hr[0]}x{hr[1]}x{hr[2]} crop (LR 8x16x16), {sec:.2f} s/step; the 80x320x320 "
+                      f"on BASELINE configs[0]'s volume: LR {hr[0] // scale}x{hr[1] // scale}x{hr[2] // scale} -> 2x -> HR "
+                      f"{hr[0]}x{hr[1]}x{hr[2]}, batch 1, {sec:.2f} s/step; the 80x320x320 "
                       f"volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
 
 
@@ -271,7 +275,7 @@ def main():
     if not args.no_secondary and not args.graph and os.environ.get("SR3D_SPLIT_F16", "1") != "0":
         prev = os.environ.get("SR3D_SPLIT_F16")
         os.environ["SR3D_SPLIT_F16"] = "0"
-        fp32_only = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, min(args.steps, 5), 1)
+        fp32_only = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, args.steps, args.warmup)
         if prev is None:
             del os.environ["SR3D_SPLIT_F16"]
         else:
@@ -305,7 +309,7 @@ def main():
                            "source": os.path.relpath(tj, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         if split:
             kernel_desc = ("stride-1 conv forward + input gradient on hconv_kernel: direct implicit GEMM on "
-                           "v_mfma_f32_32x32x16_f16, fp32 operands split into two fp16 halves (3 products), fp32 accumulate")
+                           "v_mfma_f32_16x16x32_f16, fp32 operands split into two fp16 halves (3 products), fp32 accumulate")
             note = ("achieved = f16 MFMA FLOPs the kernel EXECUTES per second = 3 x algorithmic FLOPs of the 3x3x3 "
                     "convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d); channel padding to 16 not counted) / kernel "
                     "time from HIP events; peak = dense f16 MFMA at 2.4 GHz.  The f16 MFMA is POWER-bound on this part: "
@@ -352,7 +356,7 @@ def main():
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s",
-                         "frac": executed / peak, "traffic": traffic,
+                         "frac": executed / peak, "frac_algorithmic": algo / peak, "traffic": traffic,
                          "kernel": kernel_desc,
                          "note": note,
                          "algorithmic_tflops": algo,
@@ -383,11 +387,11 @@ def main():
                         "loss_kernels_gbytes_per_s": (sp["loss"]["work"] / (sp["loss"]["ms"] * 1e-3) / 1e9
                                                       if sp["loss"]["ms"] > 0 else 0.0)}
         if fp32_only is not None:
-            n5 = min(args.steps, 5)
+            n5 = args.steps
             fd = fp32_only["prof"]["igemm_s1"]
             out["fp32_mfma_only"] = {"note": "same workload with SR3D_SPLIT_F16=0 (fp32 MFMA kernels only: Winograd stride 1, direct stride 2)",
                                      "value": fp32_only["voxels_per_step"] * n5 / fp32_only["elapsed"], "unit": "HR voxels/s",
-                                     "steps": n5, "warmup": 1, "ms_per_step": fp32_only["elapsed"] / n5 * 1e3,
+                                     "steps": n5, "warmup": args.warmup, "ms_per_step": fp32_only["elapsed"] / n5 * 1e3,
                                      "loss": fp32_only["loss"],
                                      "wino_kernel_frac_of_fp32_mfma_peak": (fd["work"] / (fd["ms"] * 1e-3) / 1e12 / 2.25 /
                                                                             FP32_MFMA_PEAK_TFLOPS if fd["ms"] > 0 else 0.0)}
