@@ -14,7 +14,9 @@
 // It marches along y: per step ONE new X row of each of the 3 z planes (4 y slots per plane in LDS) and one dY row
 // (3 shifted copies, double-buffered) are staged, by waves 0-5 (X) and 6-9 (dY), one 8-voxel piece per thread,
 // loaded a step ahead into registers, then scaled, split and written; one barrier per step.
-// Scales: one power of two per tensor from max|x| / max|dY| (separate pass, sr3d_absmax): exact, no overflow.
+// Scales: one power of two per tensor SLICE of the virtual concats from max|x_i| / max|dY_i| (separate pass,
+// sr3d_absmax): exact, no overflow; the feature and gate gradients of a gated layer, or features and the building mask,
+// differ by orders of magnitude and each keeps its own 22 bits.
 // The f16 MFMA's truncation bias (sr3d_hconv.hip) is cancelled by flipping the sign of the dY rows and of the
 // accumulators every 32 rows.  Partial sums per (split, x segment) go to a slab [.][tap][n][c]; a second kernel adds them
 // in a fixed order (deterministic), undoes the scaling and writes dW[n][c][tap].
@@ -59,7 +61,7 @@ struct HwParams {
   long long rows_per_split;  // (b, z, y) rows per split
   int Npad, Cpad;
   float* slab;               // [S * nseg][27][Npad][Cpad]
-  const float* amax;         // [0] = max|x|, [1] = max|dy|
+  const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
 };
 
 template <int RT>
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   const int x0 = seg * 32;
   const long long YX = (long long)p.Y * p.X, ZYX = YX * p.Z;
 
-  const float mx = ldexpf(1.f, scale_exp_of(p.amax[0])), md = ldexpf(1.f, scale_exp_of(p.amax[1]));
+  float mx = 1.f, md = 1.f;   // this thread's staging item: scale of ITS slice
 
   // ---- staging role of this thread (fixed for the whole kernel)
   //   waves 0..5: X item  = (plane dz 0..2, channel 0..31, piece q 0..3)
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       const int si = cat_find(p.x, c);
       src = cat_ptr(p.x, si) + (long long)(c - cat_cbeg(p.x, si)) * ZYX;
       src_b = cat_bstride(p.x, si);
+      mx = ldexpf(1.f, scale_exp_of(p.amax[si]));
       it_on = x0 + 8 * it_q < p.X;
     }
   } else {
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         const int si = cat_find(p.dy, n);
         src = cat_ptr(p.dy, si) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX;
         src_b = cat_bstride(p.dy, si);
+        md = ldexpf(1.f, scale_exp_of(p.amax[4 + si]));
         it_on = x0 + 8 * it_q < p.X;
       }
     }
@@ -278,16 +282,22 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     run(std::false_type{});
 }
 
-// dW[n][c][tap] = 2^-(sx+sd) * sum_s slab[s][tap][n][c]; one thread per output, c fastest (coalesced slab reads)
+struct HwSliceMap {
+  int xcb[SR3D_MAX_SRC], dcb[SR3D_MAX_SRC];   // first channel / row of every slice (INT_MAX: unused)
+};
+
+// dW[n][c][tap] = 2^-(sx(c)+sd(n)) * sum_s slab[s][tap][n][c]; one thread per output, c fastest (coalesced slab reads)
 __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int N,
-                                                            int cu, int ldc, int Npad, int Cpad, const float* amax) {
-  const float mult = ldexpf(1.f, -(scale_exp_of(amax[0]) + scale_exp_of(amax[1])));
+                                                            int cu, int ldc, int Npad, int Cpad, const float* amax,
+                                                            const HwSliceMap sm) {
   const long long plane = (long long)Npad * Cpad;
   const long long total = (long long)N * cu * 27;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(e % cu);
     const long long r = e / cu;
     const int n = (int)(r % N), tap = (int)(r / N);
+    const int xi = (c >= sm.xcb[1]) + (c >= sm.xcb[2]) + (c >= sm.xcb[3]), di = (n >= sm.dcb[1]) + (n >= sm.dcb[2]) + (n >= sm.dcb[3]);
+    const float mult = ldexpf(1.f, -(scale_exp_of(amax[xi]) + scale_exp_of(amax[4 + di])));
     const float* s0 = slab + (long long)tap * plane + (long long)n * Cpad + c;
     float s = 0.f;
     int k = 0;
@@ -356,9 +366,9 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   {
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     for (int i = 0; i < x.n; i++)
-      if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax, st)) return rc;
+      if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax + i, st)) return rc;
     for (int i = 0; i < dy.n; i++)
-      if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 1, st)) return rc;
+      if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 4 + i, st)) return rc;
     SR3D_HIP(hipGetLastError());
   }
   HwParams p{};
@@ -388,8 +398,10 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
   const long long total = (long long)n_total * c_used * 27;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  HwSliceMap sm;
+  for (int i = 0; i < SR3D_MAX_SRC; i++) sm.xcb[i] = x.cbeg[i], sm.dcb[i] = dy.cbeg[i];
   hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, n_total, c_used,
-                     d->Cin, g.Npad, g.Cpad, (const float*)amax);
+                     d->Cin, g.Npad, g.Cpad, (const float*)amax, sm);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

@@ -71,8 +71,17 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         logging.basicConfig(level=logging.INFO, handlers=[
             logging.StreamHandler(sys.stdout), logging.FileHandler(os.path.join(os.path.dirname(weight_path), "log.txt"))])
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    # RCCL ("nccl" under PyTorch-ROCm), one GPU per rank.  SR3D_DIST_BACKEND=gloo keeps the ranks on the CPU: the
+    # multi-process rehearsal of this function's control flow (tests/test_dist_paths_gloo.py, with a stub engine -- the
+    # HIP engine itself has no CPU path and raises).
+    backend = os.environ.get("SR3D_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        device = torch.device("cuda", rank)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
     set_seeds(config["train"]["seed"])
     use_grad_norm = "grad_norm" in config["train"]
 
@@ -88,9 +97,9 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         scale_factor=config["data"].get("scale_factor", 4),
         # engine extension (absent from the reference's YAML = off): normalise / clamp / NaN-fill on the GPU, one batch
         # ahead of the step (src/device_pipeline.py); the batches are bit-identical to the CPU pipeline's
-        device_pipeline=torch.device("cuda", rank) if config["data"].get("device_pipeline", False) else None)
+        device_pipeline=device if config["data"].get("device_pipeline", False) else None)
 
-    model = sr3d_amd.make_model(config).to(rank)
+    model = sr3d_amd.make_model(config).to(device)
     loss_fn = sr3d_amd.make_loss(config)
     # engine extension (absent from the reference's YAML = off): `train: {hip_graph: true}` replays the training step as a
     # hipGraph (src/graph.py; one GPU, no GradNorm): 5 % faster at 80x320x320, 15 % on the reference's 32x64x64 crops
@@ -107,7 +116,7 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
     if use_grad_norm:
         gn = config["train"]["grad_norm"]
         grad_norm = GradNorm(n_tasks=gn["n_tasks"], alpha=gn["alpha"], output_dir_path=os.path.dirname(weight_path),
-                             device=rank, clipping_weight_min=gn.get("clipping_weight_min"))
+                             device=device if device.type == "cpu" else rank, clipping_weight_min=gn.get("clipping_weight_min"))
         optimizer = _Both(flat, torch.optim.Adam([grad_norm.weights], lr=gn["lr"]))
 
     all_scores, best_loss = [], np.inf
@@ -116,12 +125,12 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         t0 = time.time()
         dist.barrier()
         loss = train_ddp(dataloader=dataloaders["train"], sampler=samplers["train"], model=model, loss_fn=loss_fn,
-                         optimizer=optimizer, epoch=epoch, rank=rank, world_size=world_size,
+                         optimizer=optimizer, epoch=epoch, rank=device, world_size=world_size,
                          num_loops=config["train"]["num_loops_train"], grad_norm=grad_norm, reducer=reducer,
                          graph_step=graph_step)
         dist.barrier()
         val_loss = test_ddp(dataloader=dataloaders["valid"], sampler=samplers["valid"], model=model, loss_fn=loss_fn,
-                            epoch=epoch, rank=rank, world_size=world_size, num_loops=config["train"]["num_loops_valid"],
+                            epoch=epoch, rank=device, world_size=world_size, num_loops=config["train"]["num_loops_valid"],
                             grad_norm=grad_norm)
         dist.barrier()
         all_scores.append({"loss": loss, "val_loss": val_loss})

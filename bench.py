@@ -173,11 +173,15 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
         def step():  # noqa: F811
             return gstep(x, b, y)
 
+    on_gpu = torch.device(dev).type == "cuda"      # (tests/test_dist_paths_gloo.py drives this function on CPU ranks)
+
     def fence():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(warmup):
         step()
@@ -211,7 +215,8 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     if reducer is not None:
         reducer.remove_hooks()
     del model, opt, reducer, x, b, y, loss
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     return {"elapsed": float(t.item()), "prof": prof, "breakdown": breakdown, "breakdown_steps": breakdown_steps,
             "loss": last_loss, "hr": hr, "cfg": cfg,
             "voxels_per_step": world * batch * hr[0] * hr[1] * hr[2]}

@@ -428,7 +428,56 @@ def ssim_fixture():
     print("ssim.npz", {k: float(v) for k, v in out.items() if k.endswith("mean")})
 
 
+def gradnorm_fixture():
+    """N3: the reference's GradNorm (src/gradnorm.py:74-115) on the tiny model of model_tiny_a.npz: (1) ONE call of
+    GradNorm.backward with non-trivial weights / initial losses -> total, weights.grad, every parameter gradient;
+    (2) two steps of the reference's optim_helper.train with grad_norm (Adam over model + weights, renormalisation)."""
+    from src.gradnorm import GradNorm
+    z = np.load(os.path.join(OUT, "model_tiny_a.npz"))
+    cfg = json.loads(str(z["config_json"]))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    x, b, y = (torch.from_numpy(z[k]) for k in ("x", "b", "y"))
+    out = {"config_json": np.array(json.dumps(cfg)), "w0": np.array([1.0, 0.5, 2.0], dtype=np.float32),
+           "init_losses": np.array([0.1, 2.0, 0.05], dtype=np.float32), "alpha": np.array(1.5)}
+    model = make_model(cfg)
+    model.load_state_dict(sd)
+    loss_fn = make_loss(cfg)
+    gn = GradNorm(n_tasks=3, alpha=1.5, device="cpu", output_dir_path="/tmp")
+    with torch.no_grad():
+        gn.weights.copy_(torch.from_numpy(out["w0"]))
+    gn.init_losses = torch.from_numpy(out["init_losses"]).clone()
+    terms = loss_fn.calc_loss_terms(predicts=model(x, b), targets=y, masks=b)
+    model.zero_grad()
+    total = gn.backward(loss_list=list(terms), last_shared_params=model.get_last_params())
+    out["one/terms"] = npy(torch.stack(list(terms)))
+    out["one/total"] = npy(total)
+    out["one/weights_grad"] = npy(gn.weights.grad)
+    for k, p in model.named_parameters():
+        out["one/grad/" + k] = npy(p.grad)
+
+    # (2) the training loop: fresh GradNorm (weights 1, initial losses from the first batch), lr of the weights 0.025
+    model = make_model(cfg)
+    model.load_state_dict(sd)
+    gn = GradNorm(n_tasks=3, alpha=1.5, device="cpu", output_dir_path="/tmp", clipping_weight_min=0.1)
+    opt = torch.optim.Adam([{"params": model.parameters()}, {"params": gn.weights, "lr": 0.025}], lr=1e-3)
+    ds = torch.utils.data.TensorDataset(x, b[:, 0], y)
+    dl = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    avg = ref_train(dl, model, loss_fn, opt, "cpu", hide_progress_bar=True, grad_norm=gn)
+    out["loop/lr"], out["loop/lr_weights"], out["loop/clip"] = np.array(1e-3), np.array(0.025), np.array(0.1)
+    out["loop/avg_loss"] = np.array(avg)
+    out["loop/weights"] = npy(gn.weights)
+    out["loop/init_losses"] = npy(gn.init_losses)
+    for k, v in model.state_dict().items():
+        out["loop/sd2/" + k] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "gradnorm.npz"), **out)
+    print("gradnorm.npz: total", float(total), "weights.grad", gn.weights.grad if gn.weights.grad is not None else None,
+          "loop weights", out["loop/weights"], "avg", avg)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gradnorm":
+        gradnorm_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ssim":
         ssim_fixture()
         sys.exit(0)

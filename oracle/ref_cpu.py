@@ -68,7 +68,24 @@ def shuffle_voxels(x: Tensor, factor: int = 2) -> Tensor:
 # convolution building blocks  (pytorch/model/custom_conv.py:77-126, 237-306)
 # --------------------------------------------------------------------------
 class KinkRecorder(list):
-    """pass as ``kinks`` to RECORD the oracle's own activation decisions (in the format the forced mode consumes)"""
+    """pass as ``kinks`` to RECORD the oracle's own activation decisions (in the format the forced mode consumes).
+
+    ``audit=True`` also keeps, per activation and in the same layout as the decision masks, the pre-activation values
+    (``.pre``) and the magnitude of the dot product behind each of them, ``sum_k |w_k| |x_k| + |bias|`` (``.scale``):
+    what a test needs to show that a decision another fp32 evaluation took differently sat within rounding distance of
+    the kink (tests/test_gpu_default_width.py)."""
+
+    def __init__(self, audit: bool = False):
+        super().__init__()
+        self.audit = bool(audit)
+        self.pre: List[Tensor] = []
+        self.scale: List[Tensor] = []
+
+
+def _audit_scale(kinks, x: Tensor, w: Tensor, b: Optional[Tensor], stride: int, unshuffle: bool = False) -> None:
+    if isinstance(kinks, KinkRecorder) and kinks.audit:
+        s = F.conv3d(x.detach().abs(), w.detach().abs(), None if b is None else b.detach().abs(), stride=stride, padding=1)
+        kinks.scale.append(unshuffle_voxels(s, 2) if unshuffle else s)
 
 
 def _act(name: Optional[str], x: Tensor, kinks=None) -> Tensor:
@@ -81,6 +98,8 @@ def _act(name: Optional[str], x: Tensor, kinks=None) -> Tensor:
         return x
     if isinstance(kinks, KinkRecorder):
         kinks.append(x.detach() > 0)
+        if kinks.audit:
+            kinks.pre.append(x.detach())
     elif kinks is not None:
         m = next(kinks).to(device=x.device, dtype=x.dtype)
         assert m.shape == x.shape, (m.shape, x.shape)
@@ -105,12 +124,16 @@ def conv_with_act(sd: StateDict, prefix: str, x: Tensor, stride: int,
     if conv_mode is None:
         y = F.conv3d(x, sd[prefix + ".conv.weight"], sd.get(prefix + ".conv.bias"),
                      stride=stride, padding=1)
+        if act is not None:
+            _audit_scale(kinks, x, sd[prefix + ".conv.weight"], sd.get(prefix + ".conv.bias"), stride)
         return _act(act, y, kinks)
     if conv_mode in ("g_conv", "g_conv_with_separated_bias"):
         feat = F.conv3d(x, sd[prefix + ".conv.conv3d.weight"],
                         sd.get(prefix + ".conv.conv3d.bias"), stride=stride, padding=1)
         gate = F.conv3d(x, sd[prefix + ".conv.mask_conv3d.weight"],
                         sd.get(prefix + ".conv.mask_conv3d.bias"), stride=stride, padding=1)
+        if act is not None:
+            _audit_scale(kinks, x, sd[prefix + ".conv.conv3d.weight"], sd.get(prefix + ".conv.conv3d.bias"), stride)
         return torch.sigmoid(gate) * _act(act, feat, kinks)
     raise NotImplementedError(f"{conv_mode} is not supported.")
 
@@ -135,6 +158,9 @@ def up_block(sd: StateDict, prefix: str, x1: Tensor, x2: Tensor,
     elif isinstance(kinks, KinkRecorder):
         x3 = unshuffle_voxels(F.leaky_relu(u, 0.01), 2)
         kinks.append(x3.detach() > 0)
+        if kinks.audit:
+            kinks.pre.append(unshuffle_voxels(u.detach(), 2))
+            _audit_scale(kinks, x1, sd[f"{prefix}.up.0.weight"], sd[f"{prefix}.up.0.bias"], 1, unshuffle=True)
     else:   # the decision mask is given in the unshuffled layout (that is what the fused kernel writes)
         x3 = unshuffle_voxels(_act("lrelu", u, iter([shuffle_voxels(next(kinks).float(), 2)])), 2)
     y = torch.cat([x2, x3], dim=1)
@@ -180,6 +206,7 @@ def unet_forward(sd: StateDict, model_cfg: dict, x: Tensor, b: Tensor, kinks=Non
     def latent(t: Tensor) -> Tensor:
         # unet.py:192-199: Conv3d(bias=False) + LeakyReLU, num_latent_layers times
         for i in range(int(model_cfg["num_latent_layers"])):
+            _audit_scale(kinks, t, sd[f"latent_layers.{2 * i}.weight"], None, 1)
             t = _act("lrelu", F.conv3d(t, sd[f"latent_layers.{2 * i}.weight"], None, padding=1), kinks)
         return t
 

@@ -91,56 +91,81 @@ def test_whole_model_default_widths(eng, fname):
     print(f"{fname}: worst parameter gradient with forced decisions: {worst} {forced[worst]:.2e}")
     assert forced[worst] < TOL, (worst, forced[worst])
 
-    # (2) the reference itself (golden vectors: free decisions, fp32 and fp64 runs) and the free-running oracle.
-    # Their own fp32-vs-fp64 distance (`floor`) is the scale of what a handful of flipped decisions does.
+    # (2) AUDIT of the decisions.  (1) takes the HIP path's branch decisions as given; here every one of them is held
+    # against the oracle's OWN decisions (KinkRecorder) on the same inputs.  ReLU / LeakyReLU are continuous, so a
+    # decision that falls differently changes no forward value beyond rounding -- it can only differ where the
+    # oracle's pre-activation is within rounding distance of 0.  Asserted: (a) every differing element has
+    # |pre-activation| <= KINK_C * eps * (sum_k |w_k| |x_k| + |bias|) of its own dot product (eps = 2^-24; the factor
+    # covers the rounding that the inputs accumulated over up to 23 layers), (b) the number of differing decisions is
+    # what that band predicts (<= FLIP_RATE of the elements of any activation, plus a few), not a systematic set.
+    rec = R.KinkRecorder(audit=True)
+    R.unet_forward(sd, cfg["model"], x, b, kinks=rec)
+    assert len(rec) == len(kinks) == len(rec.pre) == len(rec.scale) == len(ACT_LAYERS)
+    flips, worst_ratio = [], 0.0
+    for name, mine, theirs, pre, sc in zip(ACT_LAYERS, kinks, rec, rec.pre, rec.scale):
+        assert mine.shape == theirs.shape == pre.shape == sc.shape, name
+        diff = mine != theirs
+        n = int(diff.sum())
+        flips.append(n)
+        if n:
+            ratio = float((pre[diff].abs() / (EPS32 * sc[diff])).max())
+            worst_ratio = max(worst_ratio, ratio)
+            assert ratio <= KINK_C, (name, n, ratio)
+        assert n <= 4 + FLIP_RATE * mine.numel(), (name, n, mine.numel())
+    total_el = sum(m.numel() for m in kinks)
+    print(f"{fname}: {sum(flips)} of {total_el} activation decisions differ from the oracle's ({flips}); worst "
+          f"|pre| / (eps * sum|w||x|) among them: {worst_ratio:.2f} (bound {KINK_C})")
+
+    # (3) FREE-RUNNING agreement with the reference (golden vectors) and the oracle, at 1e-5, for every parameter
+    # whose gradient no differing decision can reach: a decision of activation i enters the gradients of layer i and
+    # of every layer BEFORE it, so the parameters of the layers after the last differing activation -- `last` always
+    # -- are the same smooth function on both sides.  For the others the tight statement is (1); they are reported.
     rp, rl, rdp, rg = R.loss_and_grads(sd, cfg, x, b, y)
     assert relerr(pred, rp) < TOL
     assert abs(float(loss.detach()) - float(rl)) <= TOL * float(rl)
     _, _, _, rg64 = R.loss_and_grads(sd64, cfg, x.double(), b.double(), y.double())
+    last_flip = max([i for i, n in enumerate(flips) if n], default=-1)
     rows, bad = [], []
     for k, g in grads.items():
         gs = sampled(g)
         g32, g64 = T_(d["grad/" + k]), T_(d["f64/grad/" + k])
-        row = {"param": k, "forced": forced[k],
+        layer = k.rsplit(".", 1)[0]
+        for suffix in (".conv.conv3d", ".conv.mask_conv3d", ".conv"):
+            if layer.endswith(suffix):
+                layer = layer[:-len(suffix)]
+        idx = ACT_LAYERS.index(layer) if layer in ACT_LAYERS else (-1 if layer == "conv0" else len(ACT_LAYERS))
+        clean = last_flip < 0 or idx > last_flip
+        row = {"param": k, "forced": forced[k], "clean": clean,
                "gold32": relerr(gs, g32), "gold64": relerr(gs, g64), "gold_floor": relerr(g32, g64),
-               "norm32": abs(float(g.double().norm()) / float(d["gradnorm/" + k]) - 1),
-               "norm64": abs(float(g.double().norm()) / float(d["f64/gradnorm/" + k]) - 1),
                "orc32": relerr(g, rg[k]), "orc64": relerr(g, rg64[k]), "orc_floor": relerr(rg[k], rg64[k])}
         rows.append(row)
-    model_floor = max(max(r["gold_floor"], r["orc_floor"]) for r in rows)
-    for row in rows:
-        fl_k = max(row["gold_floor"], row["orc_floor"], model_floor)
-        for a32, a64 in (("gold32", "gold64"), ("orc32", "orc64"), ("norm32", "norm64")):
-            if not _grad_ok(row[a32], row[a64], fl_k):
-                bad.append((row["param"], a32, row))
+        if clean and not (min(row["orc32"], row["orc64"]) < TOL and min(row["gold32"], row["gold64"]) < TOL):
+            bad.append(row)
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     tag = os.environ.get("SR3D_WINOGRAD", "1") + os.environ.get("SR3D_WINOGRAD_WGRAD", "1") + \
         ("_split" if os.environ.get("SR3D_SPLIT_F16") == "2" else "")
     with open(os.path.join(out_dir, f"default_width_grad_errors_{fname[:-4]}_{tag}.json"), "w") as f:
-        json.dump(rows, f, indent=1)
-    print(f"{fname}: free decisions: worst vs fp32 oracle {max(r['orc32'] for r in rows):.2e}, vs fp64 oracle "
-          f"{max(r['orc64'] for r in rows):.2e}, oracle fp32-vs-fp64 floor {max(r['orc_floor'] for r in rows):.2e}")
+        json.dump({"flips": dict(zip(ACT_LAYERS, flips)), "worst_kink_ratio": worst_ratio, "rows": rows}, f, indent=1)
+    nclean = sum(r["clean"] for r in rows)
+    print(f"{fname}: free decisions: {nclean} of {len(rows)} parameters behind the last differing decision, worst of them vs "
+          f"oracle {max([min(r['orc32'], r['orc64']) for r in rows if r['clean']], default=0):.2e}; all parameters: worst vs "
+          f"fp32 oracle {max(r['orc32'] for r in rows):.2e}, oracle fp32-vs-fp64 floor {max(r['orc_floor'] for r in rows):.2e}")
+    assert nclean >= 2          # `last.weight`, `last.bias` at the very least
     assert not bad, bad
+
+
+EPS32 = 2.0 ** -24
+KINK_C = 64.0        # differing decisions must have |pre| <= KINK_C * eps * sum|w||x| (worst observed is printed)
+FLIP_RATE = 2e-5     # expected share of elements inside that band: ~ 2 * KINK_C * eps * sqrt(27 K) * pdf(0) ~ 1e-5
+# the 23 activations in forward order (= order of ops.KINK_LOG and of the oracle's KinkRecorder)
+ACT_LAYERS = (["down%d.convs.%d" % (i, j) for i in (1, 2, 3, 4) for j in (0, 1)] +
+              ["latent_layers.0", "latent_layers.2", "latent_layers.4"] +
+              [n for i in (4, 3, 2, 1) for n in ("up%d.up.0" % i, "up%d.convs.0" % i, "up%d.convs.1" % i)])
 
 
 def T_(a):
     return torch.from_numpy(a)
-
-
-ONE_FLIP = 3.5e-4   # 1 / sqrt(8.4e6): what ONE flipped decision among up1.up.0's outputs does to its bias gradient
-
-
-def _grad_ok(e32, e64, floor):
-    """Free-running comparison of a parameter gradient with the reference.  It passes at 1e-5 when no decision
-    differs.  At these widths the reference's OWN fp32 gradient is up to 5e-3 away from its fp64 run (`floor`): a
-    handful of ReLU / LeakyReLU decisions on pre-activations within rounding distance of 0 fall differently, and one
-    flipped decision in a level-4 layer (32k elements) moves every gradient upstream of it by ~1/sqrt(32k).  Any
-    other correct fp32 evaluation is a fresh draw of the same heavy-tailed lottery (observed: up to 4.3x the floor
-    of the same parameter), so this is only a net for gross errors -- a wrong tile or tap shows up as O(0.1 .. 1):
-    the bound is 10x the model's worst floor and never below the effect of a single flip in the largest layer.  The tight 1e-5 statement is
-    test (1) above, where the decisions are forced to agree (worst observed there: 6e-6)."""
-    return e32 < TOL or e64 <= max(ONE_FLIP, 10.0 * floor)
 
 
 # (name, Cin, Cout, stride, grid, gated, act, unshuffle, split): split = channel counts of the virtual concat and

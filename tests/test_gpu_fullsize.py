@@ -211,6 +211,73 @@ def test_batch4_unshuffle_conv_beyond_2g_elements(eng):
     assert relerr(bias.grad, bcr.grad) < TOL
 
 
+@pytest.mark.parametrize("name,cs,cout,gated,grid", [
+    ("up1.convs.0", [64, 1, 129], 64, False, FULL),             # 194 -> 64 over three slices, LeakyReLU
+    ("down1.convs.1", [128], 128, True, (40, 160, 160)),        # gated 128 -> 128, ReLU
+])
+def test_hconv_launch_shapes_vs_oracle_windows_at_full_size(eng, name, cs, cout, gated, grid):
+    """hconv_kernel at BASELINE size against the ORACLE (not against another HIP engine): the two heaviest launch
+    shapes besides up1.up.0 -- forward windows (corner, far corner, interior), then, with dy supported in an interior
+    window, the input gradient of every slice (zero outside the window's 1-voxel dilation, equal to the oracle's on the
+    cropped problem inside), the weight gradient and the bias gradient.  reference: unet.py:72-97, custom_conv.py:111-126"""
+    g = torch.Generator(device=DEV).manual_seed(41 + cout)
+    cin = sum(cs)
+    xs = [((torch.rand(1, c, *grid, generator=g, device=DEV) - 0.5) if c > 1 else
+           (torch.rand(1, 1, *grid, generator=g, device=DEV) > 0.2).float()).requires_grad_(c > 1) for c in cs]
+    std = (2.0 / (27 * cin)) ** 0.5
+    wf = (torch.randn(cout, cin, 3, 3, 3, generator=g, device=DEV) * std).requires_grad_(True)
+    wg = (torch.randn(cout, cin, 3, 3, 3, generator=g, device=DEV) * std).requires_grad_(True)
+    bias = (torch.randn(cout, generator=g, device=DEV) * 0.1).requires_grad_(True)
+    if gated:
+        y = eng.ops.gated_conv3d_act(xs, wf, wg, None, bias, act="relu", stride=1)
+    else:
+        y = eng.ops.conv3d_act(xs, wf, bias, act="lrelu", stride=1)
+    wfc, wgc, bc = wf.detach().cpu(), wg.detach().cpu(), bias.detach().cpu()
+
+    def oracle(xc, wf_, wg_, b_):
+        if gated:
+            pre = F.conv3d(xc, wf_, None)
+            return torch.sigmoid(F.conv3d(xc, wg_, b_)) * F.relu(pre), pre
+        pre = F.conv3d(xc, wf_, b_)
+        return F.leaky_relu(pre, 0.01), pre
+
+    def crop_in(lo, hi):
+        ilo, ihi = [max(0, l - 1) for l in lo], [min(f, h + 1) for h, f in zip(hi, grid)]
+        xc = torch.cat([_crop(x.detach(), ilo, ihi) for x in xs], 1).cpu()
+        pad = []
+        for dd in (2, 1, 0):
+            pad += [1 if lo[dd] - 1 < 0 else 0, 1 if hi[dd] + 1 > grid[dd] else 0]
+        return F.pad(xc, pad), ilo, ihi
+
+    far = tuple(f - d for f, d in zip(grid, (3, 6, 34)))
+    mid = (grid[0] // 2 - 3, grid[1] // 2 + 1, grid[2] // 2 - 17)
+    for lo, hi in [((0, 0, 0), (3, 5, 36)), (far, grid), (mid, tuple(m + d for m, d in zip(mid, (5, 6, 35))))]:
+        xc, _, _ = crop_in(lo, hi)
+        ref, _ = oracle(xc, wfc, wgc, bc)
+        assert relerr(_crop(y.detach(), lo, hi).cpu(), ref) < TOL, (name, lo)
+
+    lo, hi = mid, tuple(m + d for m, d in zip(mid, (5, 6, 35)))
+    xc, ilo, ihi = crop_in(lo, hi)
+    xcr, wfr, wgr, br = (t.clone().requires_grad_(True) for t in (xc, wfc, wgc, bc))
+    ref, pre = oracle(xcr, wfr, wgr, br)
+    dyc = (torch.rand(ref.shape) - 0.5) * (pre.detach().abs() > 1e-5).float()    # no gradient through the kink
+    ref.backward(dyc)
+    dy = torch.zeros_like(y)
+    dy[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = dyc.to(DEV)
+    y.backward(dy)
+    c0 = 0
+    for x, c in zip(xs, cs):
+        if x.requires_grad:
+            outside = x.grad.clone()
+            outside[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1], ilo[2]:ihi[2]] = 0
+            assert float(outside.abs().max()) == 0.0, (name, c)
+            assert relerr(_crop(x.grad, ilo, ihi), xcr.grad[:, c0:c0 + c]) < TOL, (name, c)
+        c0 += c
+    assert relerr(wf.grad, wfr.grad) < TOL and relerr(bias.grad, br.grad) < TOL, name
+    if gated:
+        assert relerr(wg.grad, wgr.grad) < TOL, name
+
+
 @pytest.mark.parametrize("cs,cout,stride,gated,B,grid", [
     ([64], 64, 1, False, 1, FULL),            # up1.convs.1: 80 workgroup rounds, 10 x segments, 26 splits
     ([64, 1], 128, 2, True, 1, FULL),         # down1.convs.0 (stride 2, gated, mask slice)
