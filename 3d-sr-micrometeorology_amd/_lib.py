@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR3D_LIBRARY") or os.path.join(_HERE, "libsr3d.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}
 PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED = 0, 1, 2, 3
 ACT_CODE = {None: ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU}
 # indices into the output of sr3d_eval_metrics (include/sr3d.h: SR3D_EVAL_*)
@@ -32,7 +34,7 @@ class Slice(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("Z", C.c_int32), ("Y", C.c_int32),
-                ("X", C.c_int32), ("stride", C.c_int32)]
+                ("X", C.c_int32), ("stride", C.c_int32), ("dtype", C.c_int32)]
 
 
 # every symbol include/sr3d.h declares: name -> (restype, argtypes)
@@ -50,10 +52,10 @@ SYMBOLS = {
     "sr3d_conv3d_bwd_weight_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P]),
     "sr3d_bias_grad_workspace_bytes": (_SZ, [_I, _I, _LL]),
-    "sr3d_bias_grad": (_I, [_P, _I, _I, _LL, _P, _P, _P]),
-    "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _P]),
-    "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _P]),
-    "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sr3d_bias_grad": (_I, [_P, _I, _I, _LL, _P, _P, _I, _P]),
+    "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _P]),
+    "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _I, _P]),
+    "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sr3d_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sr3d_near_wall": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -112,29 +114,35 @@ def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def dev_ptr(t: torch.Tensor, what: str = "tensor") -> C.c_void_p:
-    """device pointer of a dense fp32 GPU tensor (None -> NULL)"""
+def dev_ptr(t: torch.Tensor, what: str = "tensor", dtype: torch.dtype = torch.float32) -> C.c_void_p:
+    """device pointer of a dense GPU tensor of the expected element type (None -> NULL)"""
     if t is None:
         return C.c_void_p(0)
     if not t.is_cuda:
         raise RuntimeError(f"{what} must live on the GPU: the sr3d engine has no CPU path")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{what} must be float32 (got {t.dtype})")
+    if t.dtype != dtype:
+        raise TypeError(f"{what} must be {dtype} (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"{what} must be contiguous")
     return C.c_void_p(t.data_ptr())
 
 
-def slices(tensors, what="srcs"):
+def slices(tensors, what="srcs", dtype: torch.dtype = torch.float32):
     """(B,C,Z,Y,X) tensors (or (channels, None) pairs for 'no gradient wanted') -> Slice array"""
     arr = (Slice * len(tensors))()
     for i, t in enumerate(tensors):
         if isinstance(t, tuple):
             arr[i].ptr, arr[i].channels = None, int(t[0])
         else:
-            arr[i].ptr, arr[i].channels = dev_ptr(t, f"{what}[{i}]").value, int(t.shape[1])
+            arr[i].ptr, arr[i].channels = dev_ptr(t, f"{what}[{i}]", dtype).value, int(t.shape[1])
     return arr
 
 
-def conv_desc(B, Cin, Cout, Z, Y, X, stride) -> ConvDesc:
-    return ConvDesc(int(B), int(Cin), int(Cout), int(Z), int(Y), int(X), int(stride))
+def conv_desc(B, Cin, Cout, Z, Y, X, stride, dtype: torch.dtype = torch.float32) -> ConvDesc:
+    if dtype not in DTYPE_CODE:
+        raise TypeError(f"the sr3d engine stores activations as float32 or bfloat16 (got {dtype})")
+    return ConvDesc(int(B), int(Cin), int(Cout), int(Z), int(Y), int(X), int(stride), DTYPE_CODE[dtype])
+
+
+def torch_dtype(desc: ConvDesc) -> torch.dtype:
+    return torch.bfloat16 if desc.dtype == DTYPE_BF16 else torch.float32

@@ -99,10 +99,11 @@ struct SrHconvParams {
   int unsh_C, Cg;
 };
 int sr3d_hconv_mode();   // SR3D_SPLIT_F16: 0 off, 1 auto (default), 2 always
-size_t sr3d_hconv_image_bytes(int rows, int K);
+// (bf: activations stored as bfloat16, one bf16 MFMA per product; sr3d_conv_desc_t.dtype == SR3D_DTYPE_BF16)
+size_t sr3d_hconv_image_bytes(int rows, int K, bool bf = false);
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
-                    const int* cbeg, void* image, hipStream_t st);
-int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st);
+                    const int* cbeg, void* image, bool bf, hipStream_t st);
+int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipStream_t st);
 // split-f16 stride-2 conv over parity classes (sr3d_hconv_s2.hip): mode 1 = forward, mode 2 = input gradient
 struct SrHconvS2Params {
   ChanCat in;          // K side (virtual concat): x (mode 1) or dy (mode 2)
@@ -129,10 +130,10 @@ struct SrHconvS2Params {
   long long cls_blk[8];
   int cZ[8], cY[8], cX[8];
 };
-size_t sr3d_hconv_s2_image_bytes(int rows, int K);
+size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf = false);
 int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
-                       const int* rbeg, const int* cbeg, void* image, hipStream_t st);
-int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, hipStream_t st);
+                       const int* rbeg, const int* cbeg, void* image, bool bf, hipStream_t st);
+int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, bool bf, hipStream_t st);
 // split-f16 weight gradient of the stride-1 layers (sr3d_hwgrad.hip); same contract as sr3d_wino_wgrad
 size_t sr3d_hwgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);
 bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy);
@@ -165,6 +166,33 @@ struct SrProfScope {
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Activations are stored as fp32 or as bfloat16 (sr3d_conv_desc_t.dtype).  Kernels that only move or reduce them, and
+// the fp32-MFMA fallback kernels, are templated on the STORAGE type and compute in fp32: bf16raw is the 16-bit pattern.
+typedef unsigned short bf16raw;
+template <typename T> struct ActIo;
+template <> struct ActIo<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }   // 16-byte aligned
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct ActIo<bf16raw> {
+  static __device__ __forceinline__ float ld(const bf16raw* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+  static __device__ __forceinline__ f32x4 ld4(const bf16raw* p) {   // 8-byte aligned
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ bf16raw rne(float v) { return __builtin_bit_cast(bf16raw, (__bf16)v); }
+  static __device__ __forceinline__ void st(bf16raw* p, float v) { *p = rne(v); }
+  static __device__ __forceinline__ void st4(bf16raw* p, f32x4 v) {
+    uint2 u;
+    u.x = (unsigned)rne(v.x) | ((unsigned)rne(v.y) << 16);
+    u.y = (unsigned)rne(v.z) | ((unsigned)rne(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+};
 
 // One-time launch setup that is a property of the DEVICE (hipFuncSetAttribute: dynamic LDS above 64 KB), keyed on the
 // current device: a process may run the engine on cuda:1 after cuda:0 from the same thread.

@@ -23,57 +23,54 @@ __device__ __forceinline__ float act_slope(float f, int act) {
   return 1.f;
 }
 
-// d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)
-__global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const float* __restrict__ dy,
-                                                                 const float* __restrict__ f,
-                                                                 const float* __restrict__ s, float* __restrict__ df,
-                                                                 float* __restrict__ dg, long long n, int act) {
+// d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)        (T: storage type, float or bf16raw; fp32 arithmetic)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ f,
+                                                                 const T* __restrict__ s, T* __restrict__ df,
+                                                                 T* __restrict__ dg, long long n, int act) {
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long long i = i0; i < n4; i += stride) {
-    const float4 a = reinterpret_cast<const float4*>(dy)[i];
-    const float4 ff = reinterpret_cast<const float4*>(f)[i];
-    const float4 ss = reinterpret_cast<const float4*>(s)[i];
-    float4 o1, o2;
-#define ONE(q)                                                          \
-  o1.q = a.q * ss.q * act_slope(ff.q, act);                              \
-  o2.q = a.q * ff.q * (ss.q * (1.f - ss.q));
-    ONE(x) ONE(y) ONE(z) ONE(w)
-#undef ONE
-    reinterpret_cast<float4*>(df)[i] = o1;
-    reinterpret_cast<float4*>(dg)[i] = o2;
+    const f32x4 a = ActIo<T>::ld4(dy + 4 * i), ff = ActIo<T>::ld4(f + 4 * i), ss = ActIo<T>::ld4(s + 4 * i);
+    f32x4 o1, o2;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      o1[q] = a[q] * ss[q] * act_slope(ff[q], act);
+      o2[q] = a[q] * ff[q] * (ss[q] * (1.f - ss[q]));
+    }
+    ActIo<T>::st4(df + 4 * i, o1);
+    ActIo<T>::st4(dg + 4 * i, o2);
   }
   for (long long i = n4 * 4 + i0; i < n; i += stride) {
-    const float a = dy[i], ff = f[i], ss = s[i];
-    df[i] = a * ss * act_slope(ff, act);
-    dg[i] = a * ff * (ss * (1.f - ss));
+    const float a = ActIo<T>::ld(dy + i), ff = ActIo<T>::ld(f + i), ss = ActIo<T>::ld(s + i);
+    ActIo<T>::st(df + i, a * ss * act_slope(ff, act));
+    ActIo<T>::st(dg + i, a * ff * (ss * (1.f - ss)));
   }
 }
 
-__global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             float* __restrict__ dp, long long n) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                             T* __restrict__ dp, long long n) {
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long long i = i0; i < n4; i += stride) {
-    const float4 a = reinterpret_cast<const float4*>(dy)[i];
-    const float4 yy = reinterpret_cast<const float4*>(y)[i];
-    float4 o;
-    o.x = yy.x > 0.f ? a.x : 0.01f * a.x;
-    o.y = yy.y > 0.f ? a.y : 0.01f * a.y;
-    o.z = yy.z > 0.f ? a.z : 0.01f * a.z;
-    o.w = yy.w > 0.f ? a.w : 0.01f * a.w;
-    reinterpret_cast<float4*>(dp)[i] = o;
+    const f32x4 a = ActIo<T>::ld4(dy + 4 * i), yy = ActIo<T>::ld4(y + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[q] = yy[q] > 0.f ? a[q] : 0.01f * a[q];
+    ActIo<T>::st4(dp + 4 * i, o);
   }
-  for (long long i = n4 * 4 + i0; i < n; i += stride) dp[i] = y[i] > 0.f ? dy[i] : 0.01f * dy[i];
+  for (long long i = n4 * 4 + i0; i < n; i += stride)
+    ActIo<T>::st(dp + i, ActIo<T>::ld(y + i) > 0.f ? ActIo<T>::ld(dy + i) : 0.01f * ActIo<T>::ld(dy + i));
 }
 
 // dpre[b][f*C + c][z][y][x] = dy[b][c][2z+fz][2y+fy][2x+fx] * lrelu'(y[same])
 // one thread per (b, c, fine z, fine y, coarse x): reads a float2 (fx = 0, 1), writes two channels
-__global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const float* __restrict__ dy,
-                                                                       const float* __restrict__ y,
-                                                                       float* __restrict__ dp, int B, int C, int Z,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                                       T* __restrict__ dp, int B, int C, int Z,
                                                                        int Y, int X) {
   const long long total = (long long)B * C * (2 * Z) * (2 * Y) * X;
   const long long czyx = (long long)Z * Y * X;
@@ -88,13 +85,20 @@ __global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const flo
     r /= 2 * Z;
     const int c = (int)(r % C);
     const int b = (int)(r / C);
-    const float2 g = reinterpret_cast<const float2*>(dy)[i];
-    const float2 v = reinterpret_cast<const float2*>(y)[i];
+    float2 g, v;
+    if constexpr (sizeof(T) == 4) {
+      g = reinterpret_cast<const float2*>(dy)[i];
+      v = reinterpret_cast<const float2*>(y)[i];
+    } else {   // two adjacent bf16: one 4-byte load each
+      const unsigned gu = reinterpret_cast<const unsigned*>(dy)[i], vu = reinterpret_cast<const unsigned*>(y)[i];
+      g = float2{__builtin_bit_cast(float, gu << 16), __builtin_bit_cast(float, gu & 0xffff0000u)};
+      v = float2{__builtin_bit_cast(float, vu << 16), __builtin_bit_cast(float, vu & 0xffff0000u)};
+    }
     const int fz = fz_ & 1, z = fz_ >> 1, fy = fy_ & 1, yy = fy_ >> 1;
     const int f0 = (fz * 2 + fy) * 2;
     const long long o = (((long long)b * 8 * C + (long long)f0 * C + c) * Z + z) * Y * X + (long long)yy * X + x;
-    dp[o] = v.x > 0.f ? g.x : 0.01f * g.x;
-    dp[o + (long long)C * czyx] = v.y > 0.f ? g.y : 0.01f * g.y;
+    ActIo<T>::st(dp + o, v.x > 0.f ? g.x : 0.01f * g.x);
+    ActIo<T>::st(dp + o + (long long)C * czyx, v.y > 0.f ? g.y : 0.01f * g.y);
   }
 }
 
@@ -372,8 +376,12 @@ __global__ __launch_bounds__(kThreads) void adam_indirect_kernel(float* __restri
 
 extern "C" {
 
+#define SR3D_DTYPE_CHECK(dtype, what) \
+  SR3D_CHECK((dtype) == SR3D_DTYPE_F32 || (dtype) == SR3D_DTYPE_BF16, SR3D_E_ARG, what ": unknown dtype %d", (dtype))
+
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
-                       long long n, int act, void* stream) {
+                       long long n, int act, int dtype, void* stream) {
+  SR3D_DTYPE_CHECK(dtype, "gated_act_bwd");
   SR3D_CHECK(dy && save_f && save_s && d_feat && d_gate && n > 0, SR3D_E_ARG, "gated_act_bwd: bad argument");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_act_bwd: unknown activation %d", act);
   SR3D_ALIGN_CHECK(dy, "gated_act_bwd");
@@ -381,35 +389,50 @@ int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, v
   SR3D_ALIGN_CHECK(save_s, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_feat, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_gate, "gated_act_bwd");
-  SrProfScope prof(SR3D_PROF_ACT_BWD, 20.0 * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
-  hipLaunchKernelGGL(gated_act_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+  const double esz = dtype == SR3D_DTYPE_BF16 ? 2.0 : 4.0;
+  SrProfScope prof(SR3D_PROF_ACT_BWD, 5.0 * esz * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
+  if (dtype == SR3D_DTYPE_BF16)
+    hipLaunchKernelGGL(gated_act_bwd_kernel<bf16raw>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16raw*)dy, (const bf16raw*)save_f, (const bf16raw*)save_s, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act);
+  else
+    hipLaunchKernelGGL(gated_act_bwd_kernel<float>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)save_f, (const float*)save_s, (float*)d_feat, (float*)d_gate, n,
                      act);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 
-int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, void* stream) {
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* stream) {
   SR3D_CHECK(dy && y && dpre && n > 0, SR3D_E_ARG, "lrelu_bwd: bad argument");
+  SR3D_DTYPE_CHECK(dtype, "lrelu_bwd");
   SR3D_ALIGN_CHECK(dy, "lrelu_bwd");
   SR3D_ALIGN_CHECK(y, "lrelu_bwd");
   SR3D_ALIGN_CHECK(dpre, "lrelu_bwd");
-  SrProfScope prof(SR3D_PROF_ACT_BWD, 12.0 * (double)n, (hipStream_t)stream);
-  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+  SrProfScope prof(SR3D_PROF_ACT_BWD, (dtype == SR3D_DTYPE_BF16 ? 6.0 : 12.0) * (double)n, (hipStream_t)stream);
+  if (dtype == SR3D_DTYPE_BF16)
+    hipLaunchKernelGGL(lrelu_bwd_kernel<bf16raw>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, n);
+  else
+    hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)y, (float*)dpre, n);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 
-int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X,
+int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X, int dtype,
                              void* stream) {
   SR3D_CHECK(dy && y && dpre && B > 0 && C > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG,
              "unshuffle_lrelu_bwd: bad argument");
+  SR3D_DTYPE_CHECK(dtype, "unshuffle_lrelu_bwd");
   SR3D_CHECK((reinterpret_cast<uintptr_t>(dy) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, SR3D_E_ARG,
              "unshuffle_lrelu_bwd: pointers must be 8-byte aligned");
   const long long total = (long long)B * C * 4 * Z * Y * X;
-  SrProfScope prof(SR3D_PROF_ACT_BWD, 12.0 * 2.0 * (double)total, (hipStream_t)stream);
-  hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+  SrProfScope prof(SR3D_PROF_ACT_BWD, (dtype == SR3D_DTYPE_BF16 ? 6.0 : 12.0) * 2.0 * (double)total, (hipStream_t)stream);
+  if (dtype == SR3D_DTYPE_BF16)
+    hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel<bf16raw>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, B, C, Z, Y, X);
+  else
+    hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel<float>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)y, (float*)dpre, B, C, Z, Y, X);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

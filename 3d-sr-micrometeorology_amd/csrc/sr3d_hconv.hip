@@ -24,6 +24,11 @@
 // independent, so the barriers and the halo refill of one are covered by the MFMAs of the other.  (One 512-thread
 // workgroup per CU on 4 x 4 x 32 voxels measured the same 58-60 % matrix-pipe utilisation: the kernel is bound by the
 // part's power limit; the small workgroups stayed because smaller launches still fill the chip.)
+// BF = true (sr3d_conv_desc_t.dtype = SR3D_DTYPE_BF16, BASELINE configs[4]): activations are STORED as bfloat16.  The same
+// kernel then needs no split and no scaling -- bf16 has fp32's exponent range, and a bf16 x bf16 product is exact in the
+// MFMA's fp32 accumulator: ONE v_mfma_f32_16x16x32_bf16 per tile and tap pair instead of three, half the halo bytes
+// from HBM, half the LDS (one part), outputs rounded to bf16 (RNE) in the epilogue.  Weights are rounded to bf16 once
+// per call by the packing kernel (fp32 master weights stay with the optimizer).
 //   halo      [part][channel half][voxel 4x6x34][8 ch] fp16 (56 KB): raw fp32 rows come in by buffer loads with
 //             hardware range checks one chunk ahead (registers), are scaled, split and written as 16-byte pieces;
 //             a B fragment is one conflict-free ds_read_b128 at (voxel + tap) * 16
@@ -49,24 +54,29 @@ constexpr int HVOX = HHZ * HHY * HHX;          // 816
 constexpr int HNR = 7;                         // staging rounds: 2 waves per channel half x 7 x 64 voxels
 constexpr int HVP = 2 * HNR * 64;              // voxels per plane, padded (896)
 constexpr int HPLANE = HVP * 16;               // bytes of one (part, channel half) plane
-constexpr int HBYTES = 4 * HPLANE;             // 57344
+constexpr int HBYTES = 4 * HPLANE;             // 57344 (split-f16: [hi | lo] x [channel half]; bf16: 2 planes)
 constexpr int HNT = 256;
 constexpr int HPH = 14;                        // weight phases per chunk: tap pairs (2p, 2p + 1); tap 27 is a zero dummy
-template <int RT>
+template <int RT, bool BF = false>
 struct HGeo {
-  static constexpr int PIECES = 2 * 2 * RT;    // 1 KB fragments of one phase: [hi | lo][16-row tile]
+  static constexpr int NP = BF ? 1 : 2;        // operand parts: [hi | lo], or the bf16 value itself
+  static constexpr int PIECES = NP * 2 * RT;   // 1 KB fragments of one phase: [part][16-row tile]
   static constexpr int WPHASE = PIECES * 1024;
-  static constexpr size_t LDS = HBYTES + 2 * (size_t)WPHASE;
+  static constexpr int HB = NP * 2 * HPLANE;   // halo bytes
+  static constexpr size_t LDS = HB + 2 * (size_t)WPHASE;
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
 
-template <int RT>
+
+template <int RT, bool BF>
 __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
-  using G = HGeo<RT>;
+  using G = HGeo<RT, BF>;
+  constexpr int NP = G::NP;
+  constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Hs = lds;
-  unsigned char* Ws = lds + HBYTES;
+  unsigned char* Ws = lds + G::HB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,9 +98,9 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const int b = blockIdx.y;
   const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
   const long long ZYX = (long long)p.Z * p.Y * p.X;
-  const int chan_bytes = (int)(ZYX * 4);
+  const int chan_bytes = (int)(ZYX * ESZ);
 
-  int sw = split_scale_exp(*p.absmax_w);
+  int sw = BF ? 0 : split_scale_exp(*p.absmax_w);
   if (sw == kSplitScaleNone) sw = 0;
   // exchange slots for the wave maxima [chunk parity][wave]: in the padding behind the 816 voxels of halo plane 0
   float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
@@ -106,14 +116,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     const int hy = r2 / HHX, hx = r2 - hy * HHX;
     const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = e < HVOX && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
-    soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
+    soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * (unsigned)ESZ : 0xffffffffu;
     swr[r] = e * 16;
   }
   // Per-slice base pointers of this sample, pinned in scalar registers: left to itself hipcc turns the slice selects into
   // dependent kernel-argument loads (two or three ~200-cycle scalar-load round trips per channel, in every wave, at the
   // start of every chunk).
   // (separate variables, not arrays: an array would be indexed in scratch memory)
-#define SR3D_SLICE_BASE(i) reinterpret_cast<unsigned long long>(p.in.ptr[i] + (long long)b * p.in.bstride[i])
+#define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
   unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
 #undef SR3D_SLICE_BASE
   int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
@@ -147,11 +157,17 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     for (int c = 0; c < 8; c++) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase[c], 0, gc0 + c < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < HNR; r++) raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
+      for (int r = 0; r < HNR; r++) {
+        if constexpr (BF)   // the 16 bits of the bf16 element, zero-extended
+          raw[r][c] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, soff[r], 0, 0));
+        else
+          raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
+      }
     }
   };
   // largest |value| among this wave's rows of the chunk in `raw` -> its exchange slot
   auto publish_max = [&](const int parity) {
+    if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
 #pragma unroll
     for (int r = 0; r < HNR; r++)
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   };
   // running scale exponent: the largest chunk magnitude seen so far decides (kSplitScaleNone until a non-zero chunk came)
   auto next_scale = [&](const int parity, const int s_run) {
+    if constexpr (BF) return 0;
     const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
     const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
@@ -171,6 +188,16 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   auto convert = [&](const float in_mult) {
 #pragma unroll
     for (int r = 0; r < HNR; r++) {
+      if constexpr (BF) {   // pack the 8 channels of a voxel: 16 bytes, the MFMA operand as it is
+        u32x4 pk;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          pk[c] = __builtin_bit_cast(unsigned, raw[r][2 * c]) | (__builtin_bit_cast(unsigned, raw[r][2 * c + 1]) << 16);
+        chi[r] = __builtin_bit_cast(h8, pk);
+        asm volatile("" : "+v"(chi[r]));
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const float sc = raw[r][c] * in_mult;
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     for (int r = 0; r < HNR; r++) {
       if (r == HNR - 1 && swr[r] >= HVOX * 16) continue;   // padding voxels: the exchange slots live there
       *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
-      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
+      if constexpr (!BF) *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
     }
   };
   // one kz phase of the packed weights: PIECES contiguous 1 KB fragments, LDS-DMA.  (The buffer form on purpose: the
@@ -260,16 +287,16 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
       // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
       const unsigned char* Hk = Hs + (tap_b ? tap_off(2 * kzy + 1) : tap_off(2 * kzy));
-      h8 fb[2][4], fa[2][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
+      h8 fb[NP][4], fa[NP][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
 #pragma unroll
-      for (int part = 0; part < 2; part++)
+      for (int part = 0; part < NP; part++)
 #pragma unroll
         for (int j = 0; j < 4; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
       // row tiles two at a time (12 LDS reads in flight at most: 16 overflow the lgkmcnt counter model)
 #pragma unroll
       for (int ih = 0; ih < NRT; ih += 2) {
 #pragma unroll
-        for (int part = 0; part < 2; part++)
+        for (int part = 0; part < NP; part++)
 #pragma unroll
           for (int i = 0; i < 2; i++)
             if (HCONV_ABL != 4 || (kzy == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
@@ -278,9 +305,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[1][j], acc[ih + i][j], 0, 0, 0);
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+            if constexpr (BF) {
+              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
+                                                                       acc[ih + i][j], 0, 0, 0);
+            } else {
+              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NP - 1][j], acc[ih + i][j], 0, 0, 0);
+              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NP - 1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+            }
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -338,10 +370,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
               const float sg = 1.f / (1.f + expf(-g));
               f = split_act(f, p.act);
               const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
-              p.y[o] = sg * f;
+              st_act<BF>(p.y, o, sg * f);
               if (p.save_f) {
-                p.save_f[o] = f;
-                p.save_s[o] = sg;
+                st_act<BF>(p.save_f, o, f);
+                st_act<BF>(p.save_s, o, sg);
               }
             }
           }
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
             const int f = n / p.unsh_C, c = n - f * p.unsh_C;
             const long long o = ((long long)b * p.unsh_C + c) * TZYX +
                                 ((long long)(2 * oz + (f >> 2)) * p.TY_ + (2 * oy + ((f >> 1) & 1))) * p.TX_ + (2 * ox + (f & 1));
-            p.y[o] = val;
+            st_act<BF>(p.y, o, val);
           }
         }
     }
@@ -377,13 +409,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         const int si = cat_find(p.out, n);
         float* base = cat_ptr(p.out, si);
         if (base == nullptr) continue;
-        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+        const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int vt = 2 * wave + (j >> 1);
           const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
-          if (oz < p.Z && oy < p.Y && ox < p.X) base[((long long)oz * p.TY_ + oy) * p.TX_ + ox] = split_act(acc[i][j][r] * out_mult + bv, p.act);
+          if (oz < p.Z && oy < p.Y && ox < p.X)
+            st_act<BF>(base, boff + ((long long)oz * p.TY_ + oy) * p.TX_ + ox, split_act(acc[i][j][r] * out_mult + bv, p.act));
         }
       }
   }
@@ -412,12 +445,13 @@ struct HPackParams {
   const float* absmax_w;
   _Float16* img;
   int Cout, Cin, kind, K, N, nchunks, nblk, RT, n_off;
+  int bf;   // 1: one bf16 part per weight (no scaling) instead of the [hi | lo] fp16 pair
   int rbeg[SR3D_MAX_SRC + 1];
   int cbeg[SR3D_MAX_SRC];
 };
 
 __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
-  const int sw = split_scale_exp(*p.absmax_w);
+  const int sw = p.bf ? 0 : split_scale_exp(*p.absmax_w);
   const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
   // items of 8 channels: (row block, chunk, 16-row tile, channel half, row, tap 0..27); tap 27 is the zero dummy
   const long long total = (long long)p.nblk * p.nchunks * 28 * p.RT * 64;
@@ -454,6 +488,7 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
       }
     }
     h8 hi, lo;
+    bf8 wb;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = chunk * HKC + h * 8 + j;
@@ -470,11 +505,17 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
       const _Float16 a = (_Float16)s;
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
+      wb[j] = (__bf16)s;
     }
     // fragment of (pair = tap / 2, part, tile): lane = row + 16 * (2 * (tap & 1) + h)  [MFMA K group = tap of the pair, half]
+    const int l = row + 16 * (2 * (tap & 1) + h);
+    if (p.bf) {
+      const long long frag = (((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * (2 * p.RT) + rt;
+      *reinterpret_cast<bf8*>(p.img + frag * 512 + l * 8) = wb;
+      continue;
+    }
     const long long frag0 = ((((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * 2 + 0) * (2 * p.RT) + rt;
     const long long frag1 = frag0 + 2 * p.RT;
-    const int l = row + 16 * (2 * (tap & 1) + h);
     *reinterpret_cast<h8*>(p.img + frag0 * 512 + l * 8) = hi;
     *reinterpret_cast<h8*>(p.img + frag1 * 512 + l * 8) = lo;
   }
@@ -509,22 +550,26 @@ int sr3d_hconv_mode() {
 }
 
 // header (64 bytes: max |w|) + region A (64-row blocks) + region B (one 32-row block)
-size_t sr3d_hconv_image_bytes(int rows, int K) {
+size_t sr3d_hconv_image_bytes(int rows, int K, bool bf) {
   int n2, n1;
   row_split(rows, &n2, &n1);
-  return 64 + (size_t)ceil_div(K, HKC) * HPH * ((size_t)n2 * HGeo<2>::WPHASE + (size_t)n1 * HGeo<1>::WPHASE);
+  const size_t w2 = bf ? HGeo<2, true>::WPHASE : HGeo<2>::WPHASE, w1 = bf ? HGeo<1, true>::WPHASE : HGeo<1>::WPHASE;
+  return 64 + (size_t)ceil_div(K, HKC) * HPH * ((size_t)n2 * w2 + (size_t)n1 * w1);
 }
 
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
-                    const int* cbeg, void* image, hipStream_t st) {
+                    const int* cbeg, void* image, bool bf, hipStream_t st) {
   unsigned* hdr = (unsigned*)image;
-  SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
-  SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
+  SrProfScope prof(SR3D_PROF_PACK, (bf ? 3.0 : 4.0) * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
-  if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
-  if (w2 != nullptr)
-    if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
+  if (!bf) {   // max |w| -> the layer's power-of-two scale (bf16 weights are not scaled)
+    SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
+    if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
+    if (w2 != nullptr)
+      if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
+  }
   HPackParams p{};
+  p.bf = bf ? 1 : 0;
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.nchunks = ceil_div(K, HKC);
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
@@ -537,7 +582,7 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
     if (p.nblk == 0) continue;
     p.RT = region == 0 ? 2 : 1;
     p.n_off = region == 0 ? 0 : n2 * 64;
-    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * HPH * (HGeo<2>::WPHASE / 2));
+    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.nchunks * HPH * ((bf ? HGeo<2, true>::WPHASE : HGeo<2>::WPHASE) / 2));
     const long long total = (long long)p.nblk * p.nchunks * 28 * p.RT * 64;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(hconv_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -546,7 +591,44 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
   return SR3D_OK;
 }
 
-int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st) {
+namespace {
+
+template <bool BF>
+int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipStream_t st) {
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2, BF>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1, BF>::LDS));
+        return SR3D_OK;
+      }))
+    return rc;
+  void* tok = nullptr;
+  if (sr3d_prof_active()) {
+    const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
+    sr3d_prof_begin(SR3D_PROF_HCONV, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
+  }
+  constexpr size_t lds2 = HGeo<2, BF>::LDS, lds1 = HGeo<1, BF>::LDS;
+  constexpr size_t wphase2 = HGeo<2, BF>::WPHASE;
+  if (n2 > 0) {
+    p.nblk = n2, p.nb_off = 0;
+    hipLaunchKernelGGL((hconv_kernel<2, BF>), dim3((unsigned)(nsp * n2), B), dim3(HNT), lds2, st, p);
+  }
+  if (n1 > 0) {
+    // region B: its blocks are 32 rows; express the offsets in the kernel's own units
+    SrHconvParams q = p;
+    q.nblk = 1, q.nb_off = 0;
+    q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * HPH * wphase2;
+    q.n_off = p.n_off + n2 * 64;
+    hipLaunchKernelGGL((hconv_kernel<1, BF>), dim3((unsigned)nsp, B), dim3(HNT), lds1, st, q);
+  }
+  sr3d_prof_end(tok, st);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
+}  // namespace
+
+int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipStream_t st) {
   SR3D_CHECK((long long)p.Z * p.Y * p.X < (1ll << 29), SR3D_E_ARG, "split-f16 conv: more than 2^29 voxels per channel");
   SR3D_CHECK(B <= 65535, SR3D_E_ARG, "split-f16 conv: batch too large");
   p.absmax_w = (const float*)image;
@@ -557,31 +639,5 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, hipStream_t st
   row_split(p.N, &n2, &n1);
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
-  static SrPerDevice setup;   // (the attribute is per device, not per thread)
-  if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1>::LDS));
-        return SR3D_OK;
-      }))
-    return rc;
-  void* tok = nullptr;
-  if (sr3d_prof_active()) {
-    const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
-    sr3d_prof_begin(SR3D_PROF_HCONV, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
-  }
-  if (n2 > 0) {
-    p.nblk = n2, p.nb_off = 0;
-    hipLaunchKernelGGL(hconv_kernel<2>, dim3((unsigned)(nsp * n2), B), dim3(HNT), HGeo<2>::LDS, st, p);
-  }
-  if (n1 > 0) {
-    // region B: its blocks are 32 rows; express the offsets in the kernel's own units
-    SrHconvParams q = p;
-    q.nblk = 1, q.nb_off = 0;
-    q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * HPH * HGeo<2>::WPHASE;
-    q.n_off = p.n_off + n2 * 64;
-    hipLaunchKernelGGL(hconv_kernel<1>, dim3((unsigned)nsp, B), dim3(HNT), HGeo<1>::LDS, st, q);
-  }
-  sr3d_prof_end(tok, st);
-  SR3D_HIP(hipGetLastError());
-  return SR3D_OK;
+  return bf ? hconv_launch_t<true>(p, B, n2, n1, nsp, st) : hconv_launch_t<false>(p, B, n2, n1, nsp, st);
 }

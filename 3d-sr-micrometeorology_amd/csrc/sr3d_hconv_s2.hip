@@ -31,10 +31,12 @@ constexpr int HVOX = 816, HVP = 896;           // plane geometry of sr3d_hconv.h
 constexpr int HPLANE = HVP * 16;
 constexpr int HBYTES = 4 * HPLANE;
 constexpr int HNT = 256;
-template <int RT>
+template <int RT, bool BF = false>
 struct SGeo {
-  static constexpr int WBUF = 2 * 2 * RT * 1024;   // one phase: up to 2 taps x 2 parts x RT fragments
-  static constexpr size_t LDS = HBYTES + 2 * (size_t)WBUF;
+  static constexpr int NP = BF ? 1 : 2;            // operand parts: [hi | lo], or the bf16 value itself (sr3d_hconv.hip)
+  static constexpr int WBUF = 2 * NP * RT * 1024;  // one phase: up to 2 taps x NP parts x RT fragments
+  static constexpr int HB = NP * 2 * HPLANE;
+  static constexpr size_t LDS = HB + 2 * (size_t)WBUF;
 };
 static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
@@ -44,12 +46,14 @@ static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU
 __host__ __device__ inline int tap_h(int mode, int par, int i) { return mode == 1 ? (par ? i : 1) : (par ? 1 - i : 0); }
 __host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
 
-template <int RT, int MODE>
+template <int RT, int MODE, bool BF>
 __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params p) {
-  using G = SGeo<RT>;
+  using G = SGeo<RT, BF>;
+  constexpr int NP = G::NP;
+  constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Hs = lds;
-  unsigned char* Ws = lds + HBYTES;
+  unsigned char* Ws = lds + G::HB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,9 +77,9 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
   if (z0 >= TZ || y0 >= TY || x0 >= TX) return;                     // (the grid is sized for the largest class)
   const long long IZYX = (long long)p.IZ * p.IY * p.IX;
-  const int chan_bytes = (int)(IZYX * 4);
+  const int chan_bytes = (int)(IZYX * ESZ);
 
-  int sw = split_scale_exp(*p.absmax_w);
+  int sw = BF ? 0 : split_scale_exp(*p.absmax_w);
   if (sw == kSplitScaleNone) sw = 0;
   float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
 
@@ -102,11 +106,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;
     }
     const bool ok = (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;
-    return ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * 4u : 0xffffffffu;
+    return ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ : 0xffffffffu;
   };
 
   // per-slice base pointers in scalar registers, mask arithmetic (see sr3d_hconv.hip)
-#define SR3D_SLICE_BASE(i) reinterpret_cast<unsigned long long>(p.in.ptr[i] + (long long)b * p.in.bstride[i])
+#define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
   unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
 #undef SR3D_SLICE_BASE
   int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
@@ -140,11 +144,17 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < HNR; r++)
-        raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, src_off(r, (kc >> 2) & 1, (kc >> 1) & 1, kc & 1), 0, 0));
+      for (int r = 0; r < HNR; r++) {
+        const unsigned so = src_off(r, (kc >> 2) & 1, (kc >> 1) & 1, kc & 1);
+        if constexpr (BF)   // the 16 bits of the bf16 element, zero-extended
+          raw[r][c] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, so, 0, 0));
+        else
+          raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0));
+      }
     }
   };
   auto publish_max = [&](const int parity) {
+    if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
 #pragma unroll
     for (int r = 0; r < HNR; r++)
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     if (lane == 0) xmax[parity * 4 + wave] = m;
   };
   auto next_scale = [&](const int parity, const int s_run) {
+    if constexpr (BF) return 0;
     const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
     const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
@@ -162,6 +173,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   auto split_and_write = [&](const float in_mult) {
 #pragma unroll
     for (int r = 0; r < HNR; r++) {
+      if constexpr (BF) {   // the 8 channels of a voxel, packed: the MFMA operand as it is
+        u32x4 pk;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          pk[c] = __builtin_bit_cast(unsigned, raw[r][2 * c]) | (__builtin_bit_cast(unsigned, raw[r][2 * c + 1]) << 16);
+        *reinterpret_cast<u32x4*>(Hs + sh * HPLANE + swr[r]) = pk;
+        continue;
+      }
       h8 hi, lo;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   int cls = cls_of(0);
   int nxp = 1 + (cls & 1);                      // taps of a phase in this chunk's class
   int woff = 0, gph = 0;
-  dma_w(0, nxp * 2 * RT, Ws);
+  dma_w(0, nxp * NP * RT, Ws);
   load_raw(0);
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -224,22 +243,22 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     const int cls_n = vc + 1 < NV ? cls_of(vc + 1) : cls;
     for (int ph = 0; ph < nph; ph++, gph++) {
       const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
-      const int wsize = nxp * 2 * RT * 1024;
+      const int wsize = nxp * NP * RT * 1024;
       const bool last = ph + 1 == nph;
-      if (!(last && vc + 1 == NV)) dma_w(woff + wsize, (last ? 1 + (cls_n & 1) : nxp) * 2 * RT, Ws + ((gph + 1) & 1) * G::WBUF);
+      if (!(last && vc + 1 == NV)) dma_w(woff + wsize, (last ? 1 + (cls_n & 1) : nxp) * NP * RT, Ws + ((gph + 1) & 1) * G::WBUF);
       __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
       if (ph == 0) load_raw(vc + 1);
       const int iz = ph / ny, iy = ph - iz * ny;
       const unsigned char* Hk = Hs + ((tap_h(MODE, pz, iz) * HHY + tap_h(MODE, py, iy)) * HHX) * 16;
-      h8 fa[2][2][RT], fb[2][2][2];   // [tap][part][row tile], [tap][part][voxel row]
+      h8 fa[2][NP][RT], fb[2][NP][2];   // [tap][part][row tile], [tap][part][voxel row]
 #pragma unroll
       for (int ix = 0; ix < 2; ix++) {
         if (ix < nxp) {
           const int hx = tap_h(MODE, px, ix);
 #pragma unroll
-          for (int part = 0; part < 2; part++) {
+          for (int part = 0; part < NP; part++) {
 #pragma unroll
-            for (int i = 0; i < RT; i++) fa[ix][part][i] = *reinterpret_cast<const h8*>(W + ((ix * 2 + part) * RT + i) * 1024);
+            for (int i = 0; i < RT; i++) fa[ix][part][i] = *reinterpret_cast<const h8*>(W + ((ix * NP + part) * RT + i) * 1024);
 #pragma unroll
             for (int j = 0; j < 2; j++) fb[ix][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + hx * 16);
           }
@@ -252,9 +271,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
           for (int i = 0; i < RT; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][1][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][1][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+              if constexpr (BF) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[ix][0][i]), __builtin_bit_cast(bf8, fb[ix][0][j]),
+                                                                   acc[i][j], 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][NP - 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][NP - 1][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+              }
             }
         }
       }
@@ -310,10 +334,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
             const float s = 1.f / (1.f + expf(-g));
             f = split_act(f, p.act);
             const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
-            p.y[o] = s * f;
+            st_act<BF>(p.y, o, s * f);
             if (p.save_f) {
-              p.save_f[o] = f;
-              p.save_s[o] = s;
+              st_act<BF>(p.save_f, o, f);
+              st_act<BF>(p.save_s, o, s);
             }
           }
         }
@@ -331,14 +355,15 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
         const int si = cat_find(p.out, n);
         float* base = cat_ptr(p.out, si);
         if (base == nullptr) continue;
-        base += (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;
+        const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int vt = 2 * wave + j;
           const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
           if (oz < TZ && oy < TY)
-            base[((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx)] = split_act(acc[i][j][r] * out_mult + bv, p.act);
+            st_act<BF>(base, boff + ((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx),
+                       split_act(acc[i][j][r] * out_mult + bv, p.act));
         }
       }
   }
@@ -352,6 +377,7 @@ struct S2PackParams {
   const float* absmax_w;
   _Float16* img;
   int Cout, Cin, kind, K, N, cpc, nblk, RT, n_off, mode;
+  int bf;   // 1: one bf16 part per weight, unscaled
   int rbeg[SR3D_MAX_SRC + 1];
   int cbeg[SR3D_MAX_SRC];
 };
@@ -365,7 +391,7 @@ __host__ __device__ inline int cls_taps_before(int cls) {
 }
 
 __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p) {
-  const int sw = split_scale_exp(*p.absmax_w);
+  const int sw = p.bf ? 0 : split_scale_exp(*p.absmax_w);
   const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
   // items: (row block, class, chunk, local tap, row tile, channel half, row); 27 taps over the 8 classes
   const long long total = (long long)p.nblk * p.cpc * 27 * p.RT * 64;
@@ -405,6 +431,7 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
       kstride = (long long)p.Cin * 27;
     }
     h8 hi, lo;
+    bf8 wb;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = cc * HKC + h * 8 + j;
@@ -421,6 +448,7 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
       const _Float16 a = (_Float16)s;
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
+      wb[j] = (__bf16)s;
     }
     // piece index inside the image
     long long piece;
@@ -428,6 +456,10 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
       piece = (long long)nb * p.cpc * 27 + (long long)cls_taps_before(cls) * p.cpc + (long long)cc * cls_taps(cls) + tl;
     } else {             // the 8 class images one after the other, each [row block][cc][local tap]
       piece = (long long)cls_taps_before(cls) * p.cpc * p.nblk + ((long long)nb * p.cpc + cc) * cls_taps(cls) + tl;
+    }
+    if (p.bf) {
+      *reinterpret_cast<bf8*>(p.img + (piece * p.RT + rt) * 512 + (h * 32 + row) * 8) = wb;
+      continue;
     }
     _Float16* dst = p.img + (piece * 2 * p.RT) * 512 + (h * 32 + row) * 8;
     *reinterpret_cast<h8*>(dst + (0 * p.RT + rt) * 512) = hi;
@@ -441,33 +473,47 @@ inline void row_split(int rows, int* n2, int* n1) {
   *n1 = (rem > 0 && rem <= 32) ? 1 : 0;
 }
 
-template <int MODE>
+template <int MODE, bool BF>
 void launch_rt(int rt, dim3 grid, hipStream_t st, const SrHconvS2Params& p) {
+  constexpr size_t lds2 = SGeo<2, BF>::LDS, lds1 = SGeo<1, BF>::LDS;
   if (rt == 2)
-    hipLaunchKernelGGL((hconv_s2_kernel<2, MODE>), grid, dim3(HNT), SGeo<2>::LDS, st, p);
+    hipLaunchKernelGGL((hconv_s2_kernel<2, MODE, BF>), grid, dim3(HNT), lds2, st, p);
   else
-    hipLaunchKernelGGL((hconv_s2_kernel<1, MODE>), grid, dim3(HNT), SGeo<1>::LDS, st, p);
+    hipLaunchKernelGGL((hconv_s2_kernel<1, MODE, BF>), grid, dim3(HNT), lds1, st, p);
+}
+
+template <bool BF>
+int set_attrs() {
+  constexpr int lds2 = (int)SGeo<2, BF>::LDS, lds1 = (int)SGeo<1, BF>::LDS;
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  return SR3D_OK;
 }
 
 }  // namespace
 
 // header (64 bytes) + region A (64-row blocks) + region B (one block of <= 32 rows); 27 taps per (row block, chunk)
-size_t sr3d_hconv_s2_image_bytes(int rows, int K) {
+size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf) {
   int n2, n1;
   row_split(rows, &n2, &n1);
-  return 64 + (size_t)ceil_div(K, HKC) * 27 * 2 * 1024 * ((size_t)n2 * 2 + (size_t)n1);
+  return 64 + (size_t)ceil_div(K, HKC) * 27 * (bf ? 1 : 2) * 1024 * ((size_t)n2 * 2 + (size_t)n1);
 }
 
 int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
-                       const int* rbeg, const int* cbeg, void* image, hipStream_t st) {
+                       const int* rbeg, const int* cbeg, void* image, bool bf, hipStream_t st) {
   unsigned* hdr = (unsigned*)image;
-  SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
-  SrProfScope prof(SR3D_PROF_PACK, 4.0 * (double)rows * K * 27 * 2, st);
+  SrProfScope prof(SR3D_PROF_PACK, (bf ? 3.0 : 4.0) * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
-  if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
-  if (w2 != nullptr)
-    if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
+  if (!bf) {
+    SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
+    if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
+    if (w2 != nullptr)
+      if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;
+  }
   S2PackParams p{};
+  p.bf = bf ? 1 : 0;
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.cpc = ceil_div(K, HKC), p.mode = mode;
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
@@ -480,7 +526,7 @@ int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, c
     if (p.nblk == 0) continue;
     p.RT = region == 0 ? 2 : 1;
     p.n_off = region == 0 ? 0 : n2 * 64;
-    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.cpc * 27 * 2 * 2 * 512);
+    p.img = body + (region == 0 ? 0 : (size_t)n2 * p.cpc * 27 * (bf ? 1 : 2) * 2 * 512);
     const long long total = (long long)p.nblk * p.cpc * 27 * p.RT * 64;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(hconv_s2_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -490,7 +536,7 @@ int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, c
 }
 
 // p: in, K, IZ/IY/IX, Z/Y/X (mode 1: output grid; mode 2: fine grid of dx), N, n_off, epilogue fields, TZ_/TY_/TX_
-int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, hipStream_t st) {
+int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B, bool bf, hipStream_t st) {
   SR3D_CHECK((long long)p.IZ * p.IY * p.IX < (1ll << 29), SR3D_E_ARG, "split-f16 conv: more than 2^29 voxels per channel");
   SR3D_CHECK(B <= 65535, SR3D_E_ARG, "split-f16 conv: batch too large");
   p.absmax_w = (const float*)image;
@@ -499,11 +545,8 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
   row_split(p.N, &n2, &n1);
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<2>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SGeo<1>::LDS));
-        return SR3D_OK;
+        if (int rc2 = set_attrs<false>()) return rc2;
+        return set_attrs<true>();
       }))
     return rc;
   int gz, gy, gx;   // tile space of the launch (mode 2: class 0 = even positions, the largest)
@@ -536,8 +579,9 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
     SrHconvS2Params q = p;
     q.nblk = nb, q.nb_off = 0;
     q.n_off = p.n_off + (region == 0 ? 0 : n2 * 64);
-    q.wimg = body + (region == 0 ? 0 : (size_t)n2 * cpc * 27 * 2 * 2 * 1024);
-    const size_t piece = (size_t)2 * rt * 1024;   // bytes of one tap (2 parts x rt fragments)
+    const size_t np = bf ? 1 : 2;
+    q.wimg = body + (region == 0 ? 0 : (size_t)n2 * cpc * 27 * np * 2 * 1024);
+    const size_t piece = np * rt * 1024;   // bytes of one tap (parts x rt fragments)
     if (mode == 1) {
       q.blk_stride = (long long)(cpc * 27 * piece);
     } else {
@@ -548,9 +592,9 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
     }
     const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
     if (mode == 1)
-      launch_rt<1>(rt, grid, st, q);
+      bf ? launch_rt<1, true>(rt, grid, st, q) : launch_rt<1, false>(rt, grid, st, q);
     else
-      launch_rt<2>(rt, grid, st, q);
+      bf ? launch_rt<2, true>(rt, grid, st, q) : launch_rt<2, false>(rt, grid, st, q);
   }
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());

@@ -37,11 +37,14 @@ constexpr int WNT = 768;
 // puts the first set on the even and the second on the odd slots: conflict-free.  (80 bytes, the first version, paired
 // row r with row r + 3 of the other K group: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE.)
 constexpr int PITCH = 96;
-constexpr int XROW = 2 * 32 * PITCH;               // one X row: [part][c 32][PITCH]
-constexpr int XBYTES = 12 * XROW;                  // 3 planes x 4 y slots
-template <int RT>
+// BF = true: x and dY are STORED as bfloat16 (sr3d_conv_desc_t.dtype): one part, no scaling, one
+// v_mfma_f32_16x16x32_bf16 per tile; the three shifted dY copies are made with v_alignbit on the packed pairs.
+template <int RT, bool BF = false>
 struct WGeo {
-  static constexpr int DCOPY = 2 * 32 * RT * PITCH;   // one shifted copy of a dY row: [part][n][PITCH]
+  static constexpr int NP = BF ? 1 : 2;                // operand parts
+  static constexpr int XROW = NP * 32 * PITCH;         // one X row: [part][c 32][PITCH]
+  static constexpr int XBYTES = 12 * XROW;             // 3 planes x 4 y slots
+  static constexpr int DCOPY = NP * 32 * RT * PITCH;   // one shifted copy of a dY row: [part][n][PITCH]
   static constexpr int DROW = 3 * DCOPY;
   static constexpr size_t LDS = XBYTES + 2 * (size_t)DROW;
   static constexpr int NDY = 32 * RT * 4;              // dY staging items per step (n, 8-voxel piece)
@@ -64,9 +67,11 @@ struct HwParams {
   const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
 };
 
-template <int RT>
+template <int RT, bool BF>
 __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
-  using G = WGeo<RT>;
+  using G = WGeo<RT, BF>;
+  constexpr int XROW = G::XROW, XBYTES = G::XBYTES;
+  constexpr int ESZ = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Xs = lds;
   unsigned char* Ds = lds + XBYTES;
@@ -92,17 +97,17 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   //   waves 6..9: dY item = (row n, piece q), 32 * RT * 4 of them
   const bool is_x = wave < 6;
   int it_c = 0, it_q = 0, it_dz = 0, it_n = 0;
-  const float* src = nullptr;      // channel / row base of sample 0 (per lane)
-  long long src_b = 0;             // elements between samples
+  const unsigned char* src = nullptr;   // channel / row base of sample 0 (per lane), as bytes
+  long long src_b = 0;                  // elements between samples
   bool it_on = false;
   if (is_x) {
     it_dz = tid / 128, it_c = (tid % 128) / 4, it_q = tid & 3;
     const int c = cb * 32 + it_c;
     if (c < p.cu) {
       const int si = cat_find(p.x, c);
-      src = cat_ptr(p.x, si) + (long long)(c - cat_cbeg(p.x, si)) * ZYX;
+      src = reinterpret_cast<const unsigned char*>(cat_ptr(p.x, si)) + (long long)(c - cat_cbeg(p.x, si)) * ZYX * ESZ;
       src_b = cat_bstride(p.x, si);
-      mx = ldexpf(1.f, scale_exp_of(p.amax[si]));
+      if constexpr (!BF) mx = ldexpf(1.f, scale_exp_of(p.amax[si]));
       it_on = x0 + 8 * it_q < p.X;
     }
   } else {
@@ -112,9 +117,9 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       const int n = nb * (32 * RT) + it_n;
       if (n < p.N) {
         const int si = cat_find(p.dy, n);
-        src = cat_ptr(p.dy, si) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX;
+        src = reinterpret_cast<const unsigned char*>(cat_ptr(p.dy, si)) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX * ESZ;
         src_b = cat_bstride(p.dy, si);
-        md = ldexpf(1.f, scale_exp_of(p.amax[4 + si]));
+        if constexpr (!BF) md = ldexpf(1.f, scale_exp_of(p.amax[4 + si]));
         it_on = x0 + 8 * it_q < p.X;
       }
     }
@@ -124,11 +129,27 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   float pv[10];   // piece: elements -1 .. 8 (X items use 0..7)
 #pragma unroll
   for (int j = 0; j < 10; j++) pv[j] = 0.f;
+  u32x4 pq = {0u, 0u, 0u, 0u};     // BF: the 8 bf16 elements of the piece as they are, and its two neighbours
+  unsigned pprev = 0u, pnext = 0u;
   // loads the piece of row (b, z, y) into pv (zeros when the row is outside the grid)
   auto load_piece = [&](const int b, const int z, const int y) {
     const bool ok = it_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
+    if constexpr (BF) {
+      if (ok) {
+        const unsigned short* r = reinterpret_cast<const unsigned short*>(src) + (long long)b * src_b + (long long)z * YX + (long long)y * p.X + xq;
+        pq = *reinterpret_cast<const u32x4*>(r);
+        if (!is_x) {
+          pprev = xq > 0 ? (unsigned)r[-1] : 0u;
+          pnext = xq + 8 < p.X ? (unsigned)r[8] : 0u;
+        }
+      } else {
+        pq = u32x4{0u, 0u, 0u, 0u};
+        pprev = pnext = 0u;
+      }
+      return;
+    }
     if (ok) {
-      const float* r = src + (long long)b * src_b + (long long)z * YX + (long long)y * p.X + xq;
+      const float* r = reinterpret_cast<const float*>(src) + (long long)b * src_b + (long long)z * YX + (long long)y * p.X + xq;
       const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
       pv[1] = a.x, pv[2] = a.y, pv[3] = a.z, pv[4] = a.w, pv[5] = c4.x, pv[6] = c4.y, pv[7] = c4.z, pv[8] = c4.w;
       if (!is_x) {
@@ -152,6 +173,26 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   // X row (plane slot, y slot) / dY buffer addresses
   auto write_piece = [&](const int yslot_x, const int dbuf, const float dsign) {
     if (!stager) return;
+    if constexpr (BF) {
+      if (is_x) {
+        *reinterpret_cast<u32x4*>(Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16) = pq;
+      } else {
+        const unsigned sm = dsign < 0.f ? 0x80008000u : 0u;   // sign flip of both bf16 halves
+        const unsigned d0 = pq[0] ^ sm, d1 = pq[1] ^ sm, d2 = pq[2] ^ sm, d3 = pq[3] ^ sm;
+        const unsigned pl = (pprev ^ (sm & 0xffffu)) << 16, nh = pnext ^ (sm & 0xffffu);
+        // copy cp holds dY[x' - cp + 1]: cp = 0 -> elements 1..8, cp = 1 -> 0..7, cp = 2 -> -1..6
+        const u32x4 c0 = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                          __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(nh, d3, 16)};
+        const u32x4 c1 = {d0, d1, d2, d3};
+        const u32x4 c2 = {__builtin_amdgcn_alignbit(d0, pl, 16), __builtin_amdgcn_alignbit(d1, d0, 16),
+                          __builtin_amdgcn_alignbit(d2, d1, 16), __builtin_amdgcn_alignbit(d3, d2, 16)};
+        unsigned char* d = Ds + dbuf * G::DROW + it_n * PITCH + it_q * 16;
+        *reinterpret_cast<u32x4*>(d) = c0;
+        *reinterpret_cast<u32x4*>(d + G::DCOPY) = c1;
+        *reinterpret_cast<u32x4*>(d + 2 * G::DCOPY) = c2;
+      }
+      return;
+    }
     if (is_x) {
       h8 hi, lo;
       split8(1, mx, hi, lo);
@@ -235,17 +276,25 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
 #pragma unroll
           for (int j = 0; j < 2; j++) {
             bq[j][0] = *reinterpret_cast<const h8*>(xb + j * 16 * PITCH);
-            bq[j][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + j * 16 * PITCH);
+            if constexpr (!BF) bq[j][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + j * 16 * PITCH);
           }
           const unsigned char* da = db + (FEW ? 2 : k) * G::DCOPY;
 #pragma unroll
           for (int i = 0; i < NT; i++) {
-            const h8 ah = *reinterpret_cast<const h8*>(da + i * 16 * PITCH), al = *reinterpret_cast<const h8*>(da + 32 * RT * PITCH + i * 16 * PITCH);
+            const h8 ah = *reinterpret_cast<const h8*>(da + i * 16 * PITCH);
+            if constexpr (BF) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][1], acc[k][i][j], 0, 0, 0);
-              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[j][0], acc[k][i][j], 0, 0, 0);
-              acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][0], acc[k][i][j], 0, 0, 0);
+              for (int j = 0; j < 2; j++)
+                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ah), __builtin_bit_cast(bf8, bq[j][0]),
+                                                                       acc[k][i][j], 0, 0, 0);
+            } else {
+              const h8 al = *reinterpret_cast<const h8*>(da + 32 * RT * PITCH + i * 16 * PITCH);
+#pragma unroll
+              for (int j = 0; j < 2; j++) {
+                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][1], acc[k][i][j], 0, 0, 0);
+                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[j][0], acc[k][i][j], 0, 0, 0);
+                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][0], acc[k][i][j], 0, 0, 0);
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -297,7 +346,7 @@ __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restr
     const long long r = e / cu;
     const int n = (int)(r % N), tap = (int)(r / N);
     const int xi = (c >= sm.xcb[1]) + (c >= sm.xcb[2]) + (c >= sm.xcb[3]), di = (n >= sm.dcb[1]) + (n >= sm.dcb[2]) + (n >= sm.dcb[3]);
-    const float mult = ldexpf(1.f, -(scale_exp_of(amax[xi]) + scale_exp_of(amax[4 + di])));
+    const float mult = amax ? ldexpf(1.f, -(scale_exp_of(amax[xi]) + scale_exp_of(amax[4 + di]))) : 1.f;   // (bf16: unscaled)
     const float* s0 = slab + (long long)tap * plane + (long long)n * Cpad + c;
     float s = 0.f;
     int k = 0;
@@ -360,10 +409,11 @@ bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
 int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw, float* ws,
                 hipStream_t st) {
   const HwPlan g = hw_plan(d, n_total, c_used);
+  const bool bf = d->dtype == SR3D_DTYPE_BF16;
   unsigned* amax = (unsigned*)ws;
-  SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
   const long long vox = (long long)d->Z * d->Y * d->X;
-  {
+  if (!bf) {   // (bf16 operands are not scaled: no maxima pass)
+    SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     for (int i = 0; i < x.n; i++)
       if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax + i, st)) return rc;
@@ -379,20 +429,30 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   p.slab = ws + 64, p.amax = (const float*)amax;
   const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
+  constexpr size_t l2 = WGeo<2>::LDS, l1 = WGeo<1>::LDS, l2b = WGeo<2, true>::LDS, l1b = WGeo<1, true>::LDS;
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGeo<2>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGeo<1>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2b));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1b));
         return SR3D_OK;
       }))
     return rc;
   (void)vox;
   {
     SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
-    if (g.rt == 2)
-      hipLaunchKernelGGL(hwgrad_kernel<2>, dim3((unsigned)nwg), dim3(WNT), WGeo<2>::LDS, st, p);
-    else
-      hipLaunchKernelGGL(hwgrad_kernel<1>, dim3((unsigned)nwg), dim3(WNT), WGeo<1>::LDS, st, p);
+    if (bf) {
+      if (g.rt == 2)
+        hipLaunchKernelGGL((hwgrad_kernel<2, true>), dim3((unsigned)nwg), dim3(WNT), l2b, st, p);
+      else
+        hipLaunchKernelGGL((hwgrad_kernel<1, true>), dim3((unsigned)nwg), dim3(WNT), l1b, st, p);
+    } else {
+      if (g.rt == 2)
+        hipLaunchKernelGGL((hwgrad_kernel<2, false>), dim3((unsigned)nwg), dim3(WNT), l2, st, p);
+      else
+        hipLaunchKernelGGL((hwgrad_kernel<1, false>), dim3((unsigned)nwg), dim3(WNT), l1, st, p);
+    }
     SR3D_HIP(hipGetLastError());
   }
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
@@ -401,7 +461,7 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   HwSliceMap sm;
   for (int i = 0; i < SR3D_MAX_SRC; i++) sm.xcb[i] = x.cbeg[i], sm.dcb[i] = dy.cbeg[i];
   hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, n_total, c_used,
-                     d->Cin, g.Npad, g.Cpad, (const float*)amax, sm);
+                     d->Cin, g.Npad, g.Cpad, bf ? (const float*)nullptr : (const float*)amax, sm);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

@@ -432,8 +432,12 @@ __global__ void pack_smalln_bwd_kernel(const float* __restrict__ w1, const float
   wp[e] = r < nrows ? w[(ci0 + r) * 27 + (26 - tp)] : 0.f;
 }
 
+// bfloat16 activations (sr3d_conv_desc_t.dtype): every convolution runs on the bf16 form of the split kernels
+// (sr3d_hconv.hip / sr3d_hconv_s2.hip, one bf16 MFMA per product), whatever its size
+inline bool is_bf(const sr3d_conv_desc_t* d) { return d->dtype == SR3D_DTYPE_BF16; }
+
 inline bool use_smalln_fwd(const sr3d_conv_desc_t* d, int kind) {
-  return kind == SR3D_PACK_FWD && d->Cout <= 4 && d->stride == 1;
+  return kind == SR3D_PACK_FWD && d->Cout <= 4 && d->stride == 1 && !is_bf(d);
 }
 
 // stride-1 convolutions (forward and input gradient) run on the Winograd kernel (sr3d_wino.hip)
@@ -446,6 +450,7 @@ inline bool use_wino(const sr3d_conv_desc_t* d) {
 // it off, =2 forces it) when the launch fills the chip: its 2 x 4 x 32-voxel workgroups come two per CU, and on the small grids of
 // U-Net levels 3-4 the Winograd kernel with its one-tile workgroups is the faster one (measured: up4.convs 0.68 vs 0.89 ms).
 inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
+  if (is_bf(d)) return d->stride == 1;
   const int mode = sr3d_hconv_mode();
   if (d->stride != 1 || K < 32 || rows < 16 || mode == 0) return false;
   if (mode == 2) return true;
@@ -454,6 +459,7 @@ inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
 }
 // ... and the stride-2 layers on its parity-class form (sr3d_hconv_s2.hip); bwd: 8 class launches over the coarse grid
 inline bool use_hconv_s2(const sr3d_conv_desc_t* d, int K, int rows) {
+  if (is_bf(d)) return d->stride == 2;
   const int mode = sr3d_hconv_mode();
   if (d->stride != 2 || K < 32 || rows < 16 || mode == 0) return false;
   if (mode == 2) return true;
@@ -680,6 +686,7 @@ int check_desc(const sr3d_conv_desc_t* d) {
              "conv desc: non-positive dimension");
   SR3D_CHECK(d->stride == 1 || d->stride == 2, SR3D_E_ARG, "conv desc: stride must be 1 or 2 (got %d)", d->stride);
   SR3D_CHECK((long long)d->Z * d->Y * d->X < (1ll << 31), SR3D_E_ARG, "conv desc: grid has >= 2^31 voxels");
+  SR3D_CHECK(d->dtype == SR3D_DTYPE_F32 || d->dtype == SR3D_DTYPE_BF16, SR3D_E_ARG, "conv desc: unknown dtype %d", d->dtype);
   return SR3D_OK;
 }
 
@@ -712,8 +719,9 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
     q.N = p.N, q.n_off = 0, q.epi = p.epi, q.act = p.act, q.bias = p.bias, q.bias2 = p.bias2;
     q.out = p.out, q.y = p.y, q.save_f = p.save_f, q.save_s = p.save_s, q.Cg = p.Cg;
     q.TZ_ = p.TZ_, q.TY_ = p.TY_, q.TX_ = p.TX_;
-    return sr3d_hconv_s2_launch(1, q, image, d->B, st);
+    return sr3d_hconv_s2_launch(1, q, image, d->B, is_bf(d), st);
   }
+  SR3D_CHECK(!is_bf(d), SR3D_E_ARG, "bf16 activations: stride-2 convolution with the unshuffle epilogue is not implemented");
   p.nchunks = ceil_div(p.K, kKC);
   const RowPlan rp = fwd_plan(d, p.N, p.epi == EPI_GATED);
   if (d->stride == 1) {
@@ -733,8 +741,8 @@ extern "C" {
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
-  if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_image_bytes(hconv_fwd_rows(d, kind), d->Cin);
-  if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_s2_image_bytes(hconv_fwd_rows(d, kind), d->Cin);
+  if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_image_bytes(hconv_fwd_rows(d, kind), d->Cin, is_bf(d));
+  if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_s2_image_bytes(hconv_fwd_rows(d, kind), d->Cin, is_bf(d));
   if (use_wino(d)) return sr3d_wino_image_floats(wino_fwd_rows(d, kind), d->Cin) * 4;
   return image_floats(ceil_div(fwd_rows(d, kind), 32), ceil_div(d->Cin, kKC), 27) * 4;
 }
@@ -753,10 +761,10 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   }
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)))
     return sr3d_hconv_pack(kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
-                           (const float*)w_gate, nullptr, nullptr, w_packed, (hipStream_t)stream);
+                           (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream);
   if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind)))
     return sr3d_hconv_s2_pack(1, kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
-                              (const float*)w_gate, nullptr, nullptr, w_packed, (hipStream_t)stream);
+                              (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream);
   if (use_wino(d))
     return sr3d_wino_pack(kind, d->Cout, d->Cin, wino_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                           (const float*)w_gate, nullptr, nullptr, (float*)w_packed, (hipStream_t)stream);
@@ -804,7 +812,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
       if (int rc = sr3d_make_cat(&ys, 1, (long long)d->Z * d->Y * d->X, d->Cout, &q.out, "y")) return rc;
       q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
     }
-    return sr3d_hconv_launch(q, w_packed, d->B, (hipStream_t)stream);
+    return sr3d_hconv_launch(q, w_packed, d->B, is_bf(d), (hipStream_t)stream);
   }
   if (use_wino(d)) {
     SrWinoParams q{};
@@ -862,7 +870,7 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
     q.bias = (const float*)bias_f, q.bias2 = (const float*)bias_g;
     q.y = (float*)y, q.save_f = (float*)save_f, q.save_s = (float*)save_s;
     q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
-    return sr3d_hconv_launch(q, w_packed, d->B, (hipStream_t)stream);
+    return sr3d_hconv_launch(q, w_packed, d->B, is_bf(d), (hipStream_t)stream);
   }
   if (use_wino(d)) {
     SrWinoParams q{};
@@ -901,9 +909,9 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   // (+ the [K][27][4] image of up to 4 remainder rows that take the VALU kernel)
   const size_t wino = use_wino(d) ? sr3d_wino_image_floats(d->Cin, n_dy * d->Cout) * 4 + (size_t)n_dy * d->Cout * 108 * 4 : 0;
   const size_t hc = use_hconv(d, n_dy * d->Cout, d->Cin)
-                        ? ((sr3d_hconv_image_bytes(d->Cin, n_dy * d->Cout) + 255) & ~(size_t)255) + (size_t)n_dy * d->Cout * 108 * 4
+                        ? ((sr3d_hconv_image_bytes(d->Cin, n_dy * d->Cout, is_bf(d)) + 255) & ~(size_t)255) + (size_t)n_dy * d->Cout * 108 * 4
                         : 0;
-  const size_t hs2 = use_hconv_s2(d, n_dy * d->Cout, d->Cin) ? sr3d_hconv_s2_image_bytes(d->Cin, n_dy * d->Cout) : 0;
+  const size_t hs2 = use_hconv_s2(d, n_dy * d->Cout, d->Cin) ? sr3d_hconv_s2_image_bytes(d->Cin, n_dy * d->Cout, is_bf(d)) : 0;
   size_t m = direct > wino ? direct : wino;
   m = m > hc ? m : hc;
   return m > hs2 ? m : hs2;
@@ -964,7 +972,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     int rem = rows % 64;
     const sr3d_slice_t& last = need[nn - 1];
     // (on the small grids of the deep levels the extra launches cost more than the padded tile)
-    if (!(rows > 64 && rem >= 1 && rem <= 4 && last.channels >= rem && (long long)d->Z * d->Y * d->X >= 500000)) rem = 0;
+    if (!(rows > 64 && rem >= 1 && rem <= 4 && last.channels >= rem && (long long)d->Z * d->Y * d->X >= 500000) || is_bf(d)) rem = 0;
     const int main_rows = rows - rem;
     float* wsm = nullptr;   // image of the remainder rows
     if (hconv) {
@@ -973,9 +981,9 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
       q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
       q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
       q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
-      if (int rc = sr3d_hconv_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
-      if (int rc = sr3d_hconv_launch(q, image, d->B, st)) return rc;
-      wsm = (float*)((unsigned char*)image + ((sr3d_hconv_image_bytes(main_rows, K) + 255) & ~(size_t)255));
+      if (int rc = sr3d_hconv_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
+      if (int rc = sr3d_hconv_launch(q, image, d->B, is_bf(d), st)) return rc;
+      wsm = (float*)((unsigned char*)image + ((sr3d_hconv_image_bytes(main_rows, K, is_bf(d)) + 255) & ~(size_t)255));
     } else {
       SrWinoParams q{};
       q.in = p.in, q.out = p.out;
@@ -1020,8 +1028,8 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     q.Z = d->Z, q.Y = d->Y, q.X = d->X;
     q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
     q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
-    if (int rc = sr3d_hconv_s2_pack(2, pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, st)) return rc;
-    return sr3d_hconv_s2_launch(2, q, image, d->B, st);
+    if (int rc = sr3d_hconv_s2_pack(2, pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
+    return sr3d_hconv_s2_launch(2, q, image, d->B, is_bf(d), st);
   }
   using C = IgemmCfg<1, 0, 1, 2, 4, 4, kKC>;
   // the 8 output-parity classes: packed one after the other, then ONE launch with blockIdx.z = class

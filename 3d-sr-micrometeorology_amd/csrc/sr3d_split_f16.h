@@ -4,6 +4,17 @@
 #include "sr3d_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// store one result as the activation element type (BF: bfloat16, round to nearest even)
+template <bool BF>
+__device__ __forceinline__ void st_act(float* base, long long idx, float v) {
+  if constexpr (BF)
+    reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+  else
+    base[idx] = v;
+}
 typedef __attribute__((address_space(3))) void* lds_p;
 
 // Exponent s with amax * 2^s in [2^13, 2^14): the largest element then splits into hi = fp16(a), lo = fp16(a - hi) with

@@ -64,7 +64,8 @@ struct WgradCfg {
   static_assert(HY * RW <= PZ && 3 * PZ <= PH, "pitches too small");
 };
 
-template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_>
+// T: storage type of x and dy (float, or bf16raw with sr3d_conv_desc_t.dtype = bf16: loaded, widened, multiplied in fp32)
+template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_, typename T>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   using C = WgradCfg<S_IN, TY, WAVES_N, CTW_>;
   constexpr int HY = C::HY, RW = C::RW, RQ = C::RQ, PZ = C::PZ, PH = C::PH, PV = C::PV, VT = C::VT, NCH = C::NCH;
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
   float* Xs = lds;
   float* Ds = lds + C::XS;
   // tables of global pointers (sample 0) and per-sample strides, filled once
-  const float** xptr = reinterpret_cast<const float**>(lds + ((C::XS + C::DS + 3) & ~3));
+  const T** xptr = reinterpret_cast<const T**>(lds + ((C::XS + C::DS + 3) & ~3));
   long long* xbs = reinterpret_cast<long long*>(xptr + NCH);
-  const float** dptr = reinterpret_cast<const float**>(xbs + NCH);
+  const T** dptr = reinterpret_cast<const T**>(xbs + NCH);
   long long* dbs = reinterpret_cast<long long*>(dptr + ROWS);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,21 +91,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
 
   if (tid < NCH) {
     const int gc = c_lo + tid;
-    const float* ptr = nullptr;
+    const T* ptr = nullptr;
     long long bs = 0;
     if (gc < p.Cin) {
       const int si = cat_find(p.x, gc);
-      ptr = cat_ptr(p.x, si) + (long long)(gc - cat_cbeg(p.x, si)) * IZYX;
+      ptr = reinterpret_cast<const T*>(cat_ptr(p.x, si)) + (long long)(gc - cat_cbeg(p.x, si)) * IZYX;
       bs = cat_bstride(p.x, si);
     }
     xptr[tid] = ptr, xbs[tid] = bs;
   } else if (tid >= 64 && tid < 64 + ROWS) {
     const int r = tid - 64, gn = nb * ROWS + r;
-    const float* ptr = nullptr;
+    const T* ptr = nullptr;
     long long bs = 0;
     if (gn < p.N) {
       const int si = cat_find(p.dy, gn);
-      ptr = cat_ptr(p.dy, si) + (long long)(gn - cat_cbeg(p.dy, si)) * OZYX;
+      ptr = reinterpret_cast<const T*>(cat_ptr(p.dy, si)) + (long long)(gn - cat_cbeg(p.dy, si)) * OZYX;
       bs = cat_bstride(p.dy, si);
     }
     dptr[r] = ptr, dbs[r] = bs;
@@ -193,21 +194,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
     for (int k = 0; k < CPW; k++) {
       const int cl = wave + 8 * k;     // wave-uniform
       const int gc = c_lo + cl;
-      gfloat_p base = nullptr;
+      const T* base = nullptr;
       if (cl < NCH && gc < p.Cin && zok) {
         const int si = cat_find(p.x, gc);
-        base = (gfloat_p)cat_ptr(p.x, si) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
+        base = reinterpret_cast<const T*>(cat_ptr(p.x, si)) + ((long long)(gc - cat_cbeg(p.x, si)) * IZYX + (long long)c_b * cat_bstride(p.x, si));
       }
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (base != nullptr && c_rowok) {
         if (VEC) {
-          v = *(const __attribute__((address_space(1))) f32x4*)(base + off);
+          v = ActIo<T>::ld4(base + off);
         } else {
           const int xs = c_ox0 * S_IN - 4 + 4 * l_q;
-          if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = base[off + 0];
-          if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = base[off + 1];
-          if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = base[off + 2];
-          if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = base[off + 3];
+          if ((unsigned)(xs + 0) < (unsigned)p.IX) v.x = ActIo<T>::ld(base + off + 0);
+          if ((unsigned)(xs + 1) < (unsigned)p.IX) v.y = ActIo<T>::ld(base + off + 1);
+          if ((unsigned)(xs + 2) < (unsigned)p.IX) v.z = ActIo<T>::ld(base + off + 2);
+          if ((unsigned)(xs + 3) < (unsigned)p.IX) v.w = ActIo<T>::ld(base + off + 3);
         }
       }
       dst[k] = v;
@@ -228,17 +229,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgradParams p) {
       const int e = (tid + i * NT) * 4;
       const int n = e / VT, vv = e % VT;
       const int oy = c_oy0 + vv / 32, ox = c_ox0 + (vv & 31);
-      const gfloat_p base = (gfloat_p)dptr[n];
+      const T* base = dptr[n];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (base != nullptr && oy < p.OY) {
-        const gfloat_p row = base + (long long)c_b * dbs[n] + ((long long)c_oz * p.OY + oy) * p.OX;
+        const T* row = base + (long long)c_b * dbs[n] + ((long long)c_oz * p.OY + oy) * p.OX;
         if (VEC) {
-          if (ox + 3 < p.OX) v = *(const __attribute__((address_space(1))) f32x4*)(row + ox);
+          if (ox + 3 < p.OX) v = ActIo<T>::ld4(row + ox);
         } else {
-          if (ox + 0 < p.OX) v.x = row[ox + 0];
-          if (ox + 1 < p.OX) v.y = row[ox + 1];
-          if (ox + 2 < p.OX) v.z = row[ox + 2];
-          if (ox + 3 < p.OX) v.w = row[ox + 3];
+          if (ox + 0 < p.OX) v.x = ActIo<T>::ld(row + ox + 0);
+          if (ox + 1 < p.OX) v.y = ActIo<T>::ld(row + ox + 1);
+          if (ox + 2 < p.OX) v.z = ActIo<T>::ld(row + ox + 2);
+          if (ox + 3 < p.OX) v.w = ActIo<T>::ld(row + ox + 3);
         }
       }
       vd[i] = v;
@@ -541,7 +542,7 @@ inline bool wino_wgrad_on() {
 }
 inline bool use_wino_wgrad(const sr3d_conv_desc_t* d, int n_total) {
   // (the kernel's buffer descriptors span 4 dY rows of one sample: 16 * Z*Y*X bytes must fit 31 bits)
-  return wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0 &&
+  return d->dtype != SR3D_DTYPE_BF16 && wino_wgrad_on() && d->stride == 1 && d->Cin >= 16 && n_total > 4 && n_total % 4 == 0 && d->X % 2 == 0 &&
          (long long)d->Z * d->Y * d->X < (1ll << 27);
 }
 // 1..4 input channels beyond a multiple of 32 (a mask concatenated to the features) would cost a whole 32-channel
@@ -560,6 +561,7 @@ inline size_t wino_wgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
 // split-f16 weight gradient (sr3d_hwgrad.hip): stride-1 layers on grids that fill the chip (SR3D_SPLIT_F16, see
 // sr3d_hconv.hip: 0 off, 1 auto, 2 always)
 inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
+  if (d->dtype == SR3D_DTYPE_BF16) return d->stride == 1 && d->X % 8 == 0;   // bf16 form of the kernel, any size
   const int mode = sr3d_hconv_mode();
   if (mode == 0 || d->stride != 1 || d->Cin < 32 || n_total < 16 || d->X % 8 != 0) return false;
   if (mode == 2) return true;
@@ -581,7 +583,7 @@ inline bool wino_wgrad_slices_ok(const sr3d_slice_t* dy_srcs, int n_dy) {
 }
 
 inline bool use_smalln(const sr3d_conv_desc_t* d, int n_total, int n_dy) {
-  return n_total <= 4 && n_dy == 1 && d->stride == 1 && d->Cin <= 65535;
+  return n_total <= 4 && n_dy == 1 && d->stride == 1 && d->Cin <= 65535 && d->dtype != SR3D_DTYPE_BF16;
 }
 
 // dW[n][j] = sum_s slab[s][n][j]  (fixed order: deterministic)
@@ -600,15 +602,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // db[c] = sum dy[b][c][:]  -- two deterministic stages
-__global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_kernel(const T* __restrict__ dy, float* __restrict__ part,
                                                           int B, int C, long long vox, int nsplit) {
   const int c = blockIdx.y, sp = blockIdx.x;
   const long long per = (vox + nsplit - 1) / nsplit;
   const long long v0 = sp * per, v1 = (v0 + per < vox ? v0 + per : vox);
   float s = 0.f;
   for (int b = 0; b < B; b++) {
-    const float* src = dy + ((long long)b * C + c) * vox;
-    for (long long v = v0 + threadIdx.x; v < v1; v += 256) s += src[v];
+    const T* src = dy + ((long long)b * C + c) * vox;
+    for (long long v = v0 + threadIdx.x; v < v1; v += 256) s += ActIo<T>::ld(src + v);
   }
   __shared__ float red[256];
   red[threadIdx.x] = s;
@@ -668,9 +671,9 @@ Plan make_plan(const sr3d_conv_desc_t* d, int n_total) {
   return pl;
 }
 
-template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_>
+template <int S_IN, int TY, int WAVES_N, bool VEC, int CTW_, typename T>
 int launch_wgrad_v(const WgradParams& p, dim3 grid, hipStream_t st) {
-  auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC, CTW_>;
+  auto kern = wgrad_kernel<S_IN, TY, WAVES_N, VEC, CTW_, T>;
   constexpr int kLds = (int)WgradCfg<S_IN, TY, WAVES_N, CTW_>::lds_bytes;
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
@@ -694,9 +697,12 @@ bool vec_ok(const WgradParams& p) {
 }
 
 template <int S_IN, int TY, int WAVES_N, int CTW_ = 7>
-int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t st) {
-  return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true, CTW_>(p, grid, st)
-                   : launch_wgrad_v<S_IN, TY, WAVES_N, false, CTW_>(p, grid, st);
+int launch_wgrad(const WgradParams& p, dim3 grid, bool bf, hipStream_t st) {
+  if (bf)
+    return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true, CTW_, bf16raw>(p, grid, st)
+                     : launch_wgrad_v<S_IN, TY, WAVES_N, false, CTW_, bf16raw>(p, grid, st);
+  return vec_ok(p) ? launch_wgrad_v<S_IN, TY, WAVES_N, true, CTW_, float>(p, grid, st)
+                   : launch_wgrad_v<S_IN, TY, WAVES_N, false, CTW_, float>(p, grid, st);
 }
 
 int bias_splits(long long vox) {
@@ -729,6 +735,8 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
   int n_total = 0;
   for (int i = 0; i < n_dy && i < SR3D_MAX_SRC; i++) n_total += dy_srcs[i].channels;
   SR3D_CHECK(n_total > 0, SR3D_E_ARG, "conv3d_bwd_weight: dy_srcs hold no channels");
+  SR3D_CHECK(d->dtype == SR3D_DTYPE_F32 || d->dtype == SR3D_DTYPE_BF16, SR3D_E_ARG, "conv3d_bwd_weight: unknown dtype %d", d->dtype);
+  const bool bf = d->dtype == SR3D_DTYPE_BF16;
   if (use_smalln(d, n_total, n_dy)) {
     const SmallNPlan sp = smalln_plan(d);
     SR3D_CHECK(workspace_bytes >= (size_t)sp.S * d->Cin * 108 * 4, SR3D_E_WORKSPACE,
@@ -813,15 +821,15 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
     sr3d_prof_begin(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)OZ * OY * OX * d->B, st, &tok);
   int rc;
   if (d->stride == 2)
-    rc = launch_wgrad<2, 1, 4>(p, grid, st);
+    rc = launch_wgrad<2, 1, 4>(p, grid, bf, st);
   else if (pl.ctw == 3)
-    rc = launch_wgrad<1, 2, 4, 3>(p, grid, st);
+    rc = launch_wgrad<1, 2, 4, 3>(p, grid, bf, st);
   else if (pl.waves_n == 8)
-    rc = launch_wgrad<1, 2, 8>(p, grid, st);
+    rc = launch_wgrad<1, 2, 8>(p, grid, bf, st);
   else if (pl.waves_n == 4)
-    rc = launch_wgrad<1, 2, 4>(p, grid, st);
+    rc = launch_wgrad<1, 2, 4>(p, grid, bf, st);
   else
-    rc = launch_wgrad<1, 2, 2>(p, grid, st);
+    rc = launch_wgrad<1, 2, 2>(p, grid, bf, st);
   sr3d_prof_end(tok, st);
   if (rc) return rc;
   const long long total = (long long)n_total * p.J;
@@ -838,12 +846,17 @@ size_t sr3d_bias_grad_workspace_bytes(int B, int C, long long voxels) {
   return (size_t)C * bias_splits(voxels) * 4;
 }
 
-int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, void* stream) {
+int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, int dtype, void* stream) {
   SR3D_CHECK(dy && db && workspace && B > 0 && C > 0 && voxels > 0, SR3D_E_ARG, "bias_grad: bad argument");
   SR3D_CHECK(C <= 65535, SR3D_E_ARG, "bias_grad: too many channels");
-  SrProfScope prof(SR3D_PROF_BIAS_GRAD, 4.0 * (double)B * C * (double)voxels, (hipStream_t)stream);
+  SR3D_CHECK(dtype == SR3D_DTYPE_F32 || dtype == SR3D_DTYPE_BF16, SR3D_E_ARG, "bias_grad: unknown dtype %d", dtype);
+  SrProfScope prof(SR3D_PROF_BIAS_GRAD, (dtype == SR3D_DTYPE_BF16 ? 2.0 : 4.0) * (double)B * C * (double)voxels, (hipStream_t)stream);
   const int ns = bias_splits(voxels);
-  hipLaunchKernelGGL(bias_partial_kernel, dim3(ns, C), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+  if (dtype == SR3D_DTYPE_BF16)
+    hipLaunchKernelGGL(bias_partial_kernel<bf16raw>, dim3(ns, C), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)dy,
+                       (float*)workspace, B, C, voxels, ns);
+  else
+    hipLaunchKernelGGL(bias_partial_kernel<float>, dim3(ns, C), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                      (float*)workspace, B, C, voxels, ns);
   SR3D_HIP(hipGetLastError());
   hipLaunchKernelGGL(bias_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -31,7 +31,8 @@ struct FewParams {
   int Mpad, vec;
 };
 
-template <int F>
+// T: storage type of both operands (float, or bf16raw: widened on load, fp32 arithmetic)
+template <int F, typename T>
 __global__ __launch_bounds__(256, F == 2 ? 2 : 1) void wgrad_few_kernel(const FewParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* halo = lds;                  // [F][6][10][36]
@@ -47,11 +48,11 @@ __global__ __launch_bounds__(256, F == 2 ? 2 : 1) void wgrad_few_kernel(const Fe
 #pragma unroll
     for (int t = 0; t < 27; t++) acc[f][t] = 0.f;
 
-  const float* mbase0 = nullptr;   // this lane's channel, sample 0
+  const T* mbase0 = nullptr;   // this lane's channel, sample 0
   long long mbs = 0;
   if (m < p.M) {
     const int si = cat_find(p.many, m);
-    mbase0 = cat_ptr(p.many, si) + (long long)(m - cat_cbeg(p.many, si)) * ZYX;
+    mbase0 = reinterpret_cast<const T*>(cat_ptr(p.many, si)) + (long long)(m - cat_cbeg(p.many, si)) * ZYX;
     mbs = cat_bstride(p.many, si);
   }
 
@@ -79,27 +80,27 @@ __global__ __launch_bounds__(256, F == 2 ? 2 : 1) void wgrad_few_kernel(const Fe
       if (f < p.few_n && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X) {
         const int c = p.few_c0 + f;
         const int si = cat_find(p.few, c);
-        v = cat_ptr(p.few, si)[(long long)b * cat_bstride(p.few, si) + (long long)(c - cat_cbeg(p.few, si)) * ZYX +
-                               ((long long)gz * p.Y + gy) * p.X + gx];
+        v = ActIo<T>::ld(reinterpret_cast<const T*>(cat_ptr(p.few, si)) + (long long)b * cat_bstride(p.few, si) +
+                         (long long)(c - cat_cbeg(p.few, si)) * ZYX + ((long long)gz * p.Y + gy) * p.X + gx);
       }
       halo[f * FHC + hz * FHP + hy * FHX + hx] = v;
     }
     __syncthreads();
     const int z = z0 + wave;
     if (z >= p.Z || mbase0 == nullptr) continue;
-    const float* mrow0 = mbase0 + (long long)b * mbs + (long long)z * p.Y * p.X;
+    const T* mrow0 = mbase0 + (long long)b * mbs + (long long)z * p.Y * p.X;
     for (int y = 0; y < FTY; y++) {
       const int gy = y0 + y;
       if (gy >= p.Y) break;
-      const float* mrow = mrow0 + (long long)gy * p.X + x0;
+      const T* mrow = mrow0 + (long long)gy * p.X + x0;
       auto load_m = [&](const int xq) {
         const int gx = x0 + 4 * xq;
         f32x4 v;
         if (p.vec && gx + 3 < p.X) {
-          v = *reinterpret_cast<const f32x4*>(mrow + 4 * xq);
+          v = ActIo<T>::ld4(mrow + 4 * xq);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = gx + j < p.X ? mrow[4 * xq + j] : 0.f;
+          for (int j = 0; j < 4; j++) v[j] = gx + j < p.X ? ActIo<T>::ld(mrow + 4 * xq + j) : 0.f;
         }
         return v;
       };
@@ -198,16 +199,16 @@ FewPlan few_plan(const sr3d_conv_desc_t* d, int M, int few_n) {
   return pl;
 }
 
-template <int F>
+template <int F, typename T>
 int launch_few(const FewParams& p, const FewPlan& pl, hipStream_t st) {
   constexpr int kLds = (F * FHC + 64 * F * 27) * 4;
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)wgrad_few_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        SR3D_HIP(hipFuncSetAttribute((const void*)wgrad_few_kernel<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         return SR3D_OK;
       }))
     return rc;
-  hipLaunchKernelGGL(wgrad_few_kernel<F>, dim3(pl.S, pl.mblk), dim3(256), kLds, st, p);
+  hipLaunchKernelGGL((wgrad_few_kernel<F, T>), dim3(pl.S, pl.mblk), dim3(256), kLds, st, p);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
@@ -233,7 +234,11 @@ int sr3d_wgrad_few(const sr3d_conv_desc_t* d, const ChanCat& many, int M, const 
   uintptr_t bits = 0;
   for (int i = 0; i < many.n; i++) bits |= reinterpret_cast<uintptr_t>(many.ptr[i]);
   p.vec = (d->X % 4 == 0) && (bits & 15) == 0;
-  int rc = pl.F == 1 ? launch_few<1>(p, pl, st) : (pl.F == 2 ? launch_few<2>(p, pl, st) : launch_few<4>(p, pl, st));
+  int rc;
+  if (d->dtype == SR3D_DTYPE_BF16)
+    rc = pl.F == 1 ? launch_few<1, bf16raw>(p, pl, st) : (pl.F == 2 ? launch_few<2, bf16raw>(p, pl, st) : launch_few<4, bf16raw>(p, pl, st));
+  else
+    rc = pl.F == 1 ? launch_few<1, float>(p, pl, st) : (pl.F == 2 ? launch_few<2, float>(p, pl, st) : launch_few<4, float>(p, pl, st));
   if (rc) return rc;
   const int total = M * pl.F * 27;
   hipLaunchKernelGGL(wgrad_few_reduce_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, st, (const float*)ws, dw, pl.S, M,

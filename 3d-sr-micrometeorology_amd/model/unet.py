@@ -66,6 +66,18 @@ class UNetSR(nn.Module):
                  bias_feat_extraction: bool, conv_mode_feat_extraction: str, conv_mode_down_block: str,
                  conv_mode_up_block: str, n_layers_in_block: int, **kwargs):
         super().__init__()
+        # Engine extension (absent from the reference's YAML = fp32, the reference's only precision):
+        # `model: {storage_dtype: bf16}` keeps every activation and activation gradient INSIDE the network in bfloat16
+        # (BASELINE configs[4]): bf16 MFMA with fp32 accumulation, half the HBM bytes and half the saved-for-backward
+        # memory.  Parameters, their gradients and the optimizer state stay fp32 (master weights); the network's
+        # inputs and its prediction are fp32 at the boundary, so losses, metrics and loaders are unchanged.
+        sd = kwargs.get("storage_dtype", None)
+        if sd in (None, "fp32", "float32"):
+            self.act_dtype = torch.float32
+        elif sd in ("bf16", "bfloat16"):
+            self.act_dtype = torch.bfloat16
+        else:
+            raise NotImplementedError(f"storage_dtype {sd!r}: the engine stores activations as fp32 or bf16")
         logger.info(f"conv_mode_feat_extraction = {conv_mode_feat_extraction}")
         logger.info(f"conv_mode_down_block = {conv_mode_down_block}")
         logger.info(f"conv_mode_up_block = {conv_mode_up_block}")
@@ -118,18 +130,22 @@ class UNetSR(nn.Module):
     def forward(self, x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         x0 = ops.upsample_cat(x, b, self.scale)  # cat[up0(x), b]; inputs carry no gradient
         b = b.detach().contiguous()
-        f0 = self.conv0([x0])
+        # the mask pyramid is a function of the mask alone: computed in fp32, each level rounded ONCE if stored as bf16
         b1 = ops.avgpool2(b)
-        f1 = self.down1([f0, b])
         b2 = ops.avgpool2(b1)
-        f2 = self.down2([f1, b1])
         b3 = ops.avgpool2(b2)
+        b4 = ops.avgpool2(b3) if not (self.down4 is None and self.up4 is None) else None
+        if self.act_dtype != torch.float32:
+            x0, b, b1, b2, b3 = (t.to(self.act_dtype) for t in (x0, b, b1, b2, b3))
+            b4 = b4.to(self.act_dtype) if b4 is not None else None
+        f0 = self.conv0([x0])
+        f1 = self.down1([f0, b])
+        f2 = self.down2([f1, b1])
         f3 = self.down3([f2, b2])
 
         if self.down4 is None and self.up4 is None:
             y = self._latent([f3, b3])
         else:
-            b4 = ops.avgpool2(b3)
             f4 = self.down4([f3, b3])
             y = self._latent([f4, b4])
             y = self.up4([y, b4], [f3, b3])
@@ -137,4 +153,5 @@ class UNetSR(nn.Module):
         y = self.up2([y, b2], [f1, b1])
         y = self.up1([y, b1], [f0, b])
         w, bias = self.last.weight, self.last.bias
-        return ops.conv3d_act([y, x0], w, bias, act=None, stride=1)
+        pred = ops.conv3d_act([y, x0], w, bias, act=None, stride=1)
+        return pred if self.act_dtype == torch.float32 else pred.float()

@@ -66,8 +66,8 @@ def _out_dim(z: int, s: int) -> int:
     return (z - 1) // s + 1
 
 
-def _empty(shape, like: torch.Tensor) -> torch.Tensor:
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _empty(shape, like: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
 
 
 def _check_srcs(srcs: Sequence[torch.Tensor]):
@@ -79,6 +79,10 @@ def _check_srcs(srcs: Sequence[torch.Tensor]):
     for s in srcs[1:]:
         if s.shape[0] != s0.shape[0] or s.shape[2:] != s0.shape[2:]:
             raise ValueError(f"concat operands disagree: {tuple(s.shape)} vs {tuple(s0.shape)}")
+        if s.dtype != s0.dtype:
+            raise TypeError(f"concat operands disagree in element type: {s.dtype} vs {s0.dtype}")
+    if s0.dtype not in L.DTYPE_CODE:
+        raise TypeError(f"activations are float32 or bfloat16 on this engine (got {s0.dtype})")
     return s0.shape[0], sum(int(s.shape[1]) for s in srcs), tuple(s0.shape[2:])
 
 
@@ -98,8 +102,8 @@ def _bias_grad(dpre: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(max(1, L.lib.sr3d_bias_grad_workspace_bytes(B, Cc, vox) // 4), dtype=torch.float32,
                      device=dpre.device)
     db = _empty((Cc,), dpre)
-    L.check(L.lib.sr3d_bias_grad(L.dev_ptr(dpre), B, Cc, vox, L.dev_ptr(db), L.dev_ptr(ws), L.stream_ptr()),
-            "sr3d_bias_grad")
+    L.check(L.lib.sr3d_bias_grad(L.dev_ptr(dpre, "dpre", dpre.dtype), B, Cc, vox, L.dev_ptr(db), L.dev_ptr(ws),
+                                 L.DTYPE_CODE[dpre.dtype], L.stream_ptr()), "sr3d_bias_grad")
     return db
 
 
@@ -107,10 +111,11 @@ def _bwd_weight(desc: L.ConvDesc, srcs, dys) -> torch.Tensor:
     n_total = sum(int(d.shape[1]) for d in dys)
     nbytes = L.lib.sr3d_conv3d_bwd_weight_workspace_bytes(C.byref(desc), n_total)
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dys[0].device)
-    dw = _empty((n_total, desc.Cin, 3, 3, 3), dys[0])
-    L.check(L.lib.sr3d_conv3d_bwd_weight(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.slices(dys, "dy_srcs"),
-                                         len(dys), L.dev_ptr(dw), L.dev_ptr(ws), nbytes, L.stream_ptr()),
-            "sr3d_conv3d_bwd_weight")
+    dw = _empty((n_total, desc.Cin, 3, 3, 3), dys[0])          # weight gradients are fp32 in both storage modes
+    dt = L.torch_dtype(desc)
+    L.check(L.lib.sr3d_conv3d_bwd_weight(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs),
+                                         L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(dw), L.dev_ptr(ws), nbytes,
+                                         L.stream_ptr()), "sr3d_conv3d_bwd_weight")
     return dw
 
 
@@ -121,8 +126,9 @@ def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dys[0].device)
     outs: List[Optional[torch.Tensor]] = [torch.empty_like(s) if n else None for s, n in zip(srcs, needs)]
     dsts = [o if o is not None else (int(s.shape[1]), None) for o, s in zip(outs, srcs)]
-    L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs"), len(dys), L.dev_ptr(w_feat),
-                                       L.dev_ptr(w_gate), L.slices(dsts, "dx_dsts"), len(dsts), L.dev_ptr(ws), nbytes,
+    dt = L.torch_dtype(desc)
+    L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(w_feat),
+                                       L.dev_ptr(w_gate), L.slices(dsts, "dx_dsts", dt), len(dsts), L.dev_ptr(ws), nbytes,
                                        L.stream_ptr()), "sr3d_conv3d_bwd_data")
     return outs
 
@@ -142,16 +148,17 @@ class Conv3dAct(torch.autograd.Function):
         if tuple(weight.shape[1:]) != (cin, 3, 3, 3):
             raise ValueError(f"weight {tuple(weight.shape)} does not match {cin} input channels / 3x3x3")
         weight = weight.contiguous()
-        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride)
+        dt = srcs[0].dtype           # storage type of the activations (float32, or bfloat16: model/unet.py storage_dtype)
+        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride, dt)
         wp = pack_weights(desc, L.PACK_FWD, weight, None)
         oz, oy, ox = _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride)
         if unshuffle:
-            y = _empty((B, cout // 8, 2 * oz, 2 * oy, 2 * ox), srcs[0])
+            y = _empty((B, cout // 8, 2 * oz, 2 * oy, 2 * ox), srcs[0], dt)
         else:
-            y = _empty((B, cout, oz, oy, ox), srcs[0])
-        L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.dev_ptr(wp),
-                                      L.dev_ptr(bias, "bias"), L.dev_ptr(y), L.ACT_CODE[act], int(bool(unshuffle)),
-                                      L.stream_ptr()), "sr3d_conv3d_fwd")
+            y = _empty((B, cout, oz, oy, ox), srcs[0], dt)
+        L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
+                                      L.dev_ptr(bias, "bias"), L.dev_ptr(y, "y", dt), L.ACT_CODE[act],
+                                      int(bool(unshuffle)), L.stream_ptr()), "sr3d_conv3d_fwd")
         if KINK_LOG is not None and act is not None:
             KINK_LOG.append((y > 0).cpu())
         ctx.desc, ctx.act, ctx.unshuffle, ctx.has_bias, ctx.nsrc = desc, act, unshuffle, bias is not None, len(srcs)
@@ -162,18 +169,20 @@ class Conv3dAct(torch.autograd.Function):
     def backward(ctx, dy):
         weight, y, *srcs = ctx.saved_tensors
         desc = ctx.desc
-        dy = dy.contiguous()
+        dt = L.torch_dtype(desc)
+        dy = dy.to(dt).contiguous()
         if ctx.unshuffle:
             B, c, z2, y2, x2 = dy.shape
-            dpre = _empty((B, 8 * c, z2 // 2, y2 // 2, x2 // 2), dy)
+            dpre = _empty((B, 8 * c, z2 // 2, y2 // 2, x2 // 2), dy, dt)
             if ctx.act != "lrelu":
                 raise NotImplementedError("unshuffle epilogue is defined with LeakyReLU (unet.py:99-108)")
-            L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy), L.dev_ptr(y), L.dev_ptr(dpre), B, c, z2 // 2,
-                                                   y2 // 2, x2 // 2, L.stream_ptr()), "sr3d_unshuffle_lrelu_bwd")
+            L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt),
+                                                   L.dev_ptr(dpre, "dpre", dt), B, c, z2 // 2, y2 // 2, x2 // 2,
+                                                   desc.dtype, L.stream_ptr()), "sr3d_unshuffle_lrelu_bwd")
         elif ctx.act == "lrelu":
             dpre = torch.empty_like(dy)
-            L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dy), L.dev_ptr(y), L.dev_ptr(dpre), dy.numel(), L.stream_ptr()),
-                    "sr3d_lrelu_bwd")
+            L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt), L.dev_ptr(dpre, "dpre", dt),
+                                         dy.numel(), desc.dtype, L.stream_ptr()), "sr3d_lrelu_bwd")
         elif ctx.act is None:
             dpre = dy
         else:
@@ -199,17 +208,19 @@ class GatedConv3dAct(torch.autograd.Function):
         if tuple(w_feat.shape) != (cout, cin, 3, 3, 3) or w_gate.shape != w_feat.shape:
             raise ValueError("gated conv: weight shapes do not match the input")
         w_feat, w_gate = w_feat.contiguous(), w_gate.contiguous()
-        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride)
+        dt = srcs[0].dtype
+        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride, dt)
         wp = pack_weights(desc, L.PACK_FWD_GATED, w_feat, w_gate)
         oshape = (B, cout, _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride))
-        y = _empty(oshape, srcs[0])
+        y = _empty(oshape, srcs[0], dt)
         need_bwd = any(ctx.needs_input_grad)
-        sf = _empty(oshape, y) if need_bwd else None
-        ss = _empty(oshape, y) if need_bwd else None
-        L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs"), len(srcs), L.dev_ptr(wp),
+        sf = _empty(oshape, y, dt) if need_bwd else None
+        ss = _empty(oshape, y, dt) if need_bwd else None
+        L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
                                             L.dev_ptr(b_feat, "feature bias"), L.dev_ptr(b_gate, "gate bias"),
-                                            L.dev_ptr(y), L.dev_ptr(sf), L.dev_ptr(ss), L.ACT_CODE[act],
-                                            L.stream_ptr()), "sr3d_gated_conv3d_fwd")
+                                            L.dev_ptr(y, "y", dt), L.dev_ptr(sf, "save_f", dt),
+                                            L.dev_ptr(ss, "save_s", dt), L.ACT_CODE[act], L.stream_ptr()),
+                "sr3d_gated_conv3d_fwd")
         if KINK_LOG is not None and act is not None:
             KINK_LOG.append((sf > 0).cpu())
         ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
@@ -220,11 +231,12 @@ class GatedConv3dAct(torch.autograd.Function):
     def backward(ctx, dy):
         w_feat, w_gate, sf, ss, *srcs = ctx.saved_tensors
         desc = ctx.desc
-        dy = dy.contiguous()
+        dt = L.torch_dtype(desc)
+        dy = dy.to(dt).contiguous()
         d_feat, d_gate = torch.empty_like(dy), torch.empty_like(dy)
-        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy), L.dev_ptr(sf), L.dev_ptr(ss), L.dev_ptr(d_feat),
-                                         L.dev_ptr(d_gate), dy.numel(), L.ACT_CODE[ctx.act], L.stream_ptr()),
-                "sr3d_gated_act_bwd")
+        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(sf, "save_f", dt), L.dev_ptr(ss, "save_s", dt),
+                                         L.dev_ptr(d_feat, "d_feat", dt), L.dev_ptr(d_gate, "d_gate", dt), dy.numel(),
+                                         L.ACT_CODE[ctx.act], desc.dtype, L.stream_ptr()), "sr3d_gated_act_bwd")
         needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
         want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dxs, dw, (dbf, dbg) = _grads_two_streams(

@@ -8,7 +8,11 @@
  * modules would call it.
  *
  * Conventions
- *  - all tensors are dense fp32, layout NCDHW = (B, C, z, y, x), x contiguous;
+ *  - all tensors are dense, layout NCDHW = (B, C, z, y, x), x contiguous.  Element type: fp32 everywhere (the
+ *    reference's precision, dataset.py:29), or -- `dtype = SR3D_DTYPE_BF16` in the convolution descriptor and in the
+ *    activation-backward / bias-gradient calls -- ACTIVATIONS AND THEIR GRADIENTS in bfloat16 (BASELINE configs[4]:
+ *    bf16 storage + bf16 MFMA with fp32 accumulation).  Weights, biases, weight / bias gradients, the loss and the
+ *    optimizer state are fp32 in both modes (fp32 master weights);
  *  - every pointer is a DEVICE pointer unless stated; the library never
  *    allocates, frees or caches device memory -- workspaces are passed in and
  *    sized by the *_bytes() queries;
@@ -36,6 +40,9 @@ enum {
   SR3D_E_WORKSPACE = -3 /* workspace too small */
 };
 
+/* element type of activations and activation gradients (see Conventions) */
+enum { SR3D_DTYPE_F32 = 0, SR3D_DTYPE_BF16 = 1 };
+
 /* activations fused into conv epilogues (custom_conv.py:111-126, unet.py:35,84,105) */
 enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */ };
 
@@ -55,6 +62,7 @@ typedef struct {
   int32_t B, Cin, Cout;
   int32_t Z, Y, X;
   int32_t stride; /* 1 or 2 */
+  int32_t dtype;  /* SR3D_DTYPE_*: element type of x / y / saved activations / dy / dx */
 } sr3d_conv_desc_t;
 
 /* kinds of packed (MFMA-tile-ordered) weight images; the two BWD kinds are built inside
@@ -107,18 +115,19 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
                            const sr3d_slice_t* dy_srcs, int n_dy, void* dw, void* workspace, size_t workspace_bytes,
                            void* stream);
 
-/* db[c] = sum_{b,voxels} dy[b,c,:]   (bias gradient); workspace >= sr3d_bias_grad_workspace_bytes */
+/* db[c] = sum_{b,voxels} dy[b,c,:]   (bias gradient, fp32); workspace >= sr3d_bias_grad_workspace_bytes.
+ * `dtype` (here and in the three activation-backward calls below): element type of dy / y / saved tensors / outputs */
 size_t sr3d_bias_grad_workspace_bytes(int B, int C, long long voxels);
-int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, void* stream);
+int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, int dtype, void* stream);
 
 /* d_feat = dy * s * act'(f),  d_gate = dy * f * s * (1 - s)      (autograd of custom_conv.py:119-123) */
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
-                       long long n, int act, void* stream);
+                       long long n, int act, int dtype, void* stream);
 /* dpre = dy * (y > 0 ? 1 : 0.01)        (autograd of nn.LeakyReLU, y = post-activation) */
-int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, void* stream);
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* stream);
 /* dpre(B, 8C, Z, Y, X) = shuffle_voxels(dy * lrelu'(y)) for y, dy of shape (B, C, 2Z, 2Y, 2X)
  * (autograd of unet.py:99-108 up to the conv) */
-int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X,
+int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X, int dtype,
                              void* stream);
 
 /* ---- small data-movement ops ------------------------------------------------ */
