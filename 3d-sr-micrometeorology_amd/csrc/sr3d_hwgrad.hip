@@ -80,7 +80,16 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < WNT / 64);
 
-  int v = blockIdx.x;
+  // workgroup -> (row block, channel block, x segment, split).  The nnb x ncb workgroups of one (segment, split) read the
+  // SAME X and dY rows: they get consecutive virtual ids, and consecutive virtual ids go to ONE XCD (hardware deals
+  // block ids round-robin over the 8 XCDs, each with its own L2), so that the group's re-reads are L2 hits of that XCD
+  // instead of eight HBM fetches (measured before: 13.8 GB fetched per launch for 2.1 GB of operands).
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int nb = v % p.nnb;
   v /= p.nnb;
   const int cb = v % p.ncb;

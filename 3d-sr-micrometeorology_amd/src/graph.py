@@ -39,6 +39,11 @@ class GraphedTrainStep:
         with torch.no_grad():
             for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev), keep):
                 dst.copy_(src)
+        # the warm-up's blocks go back to the driver: the capture allocates from its own pool, and at BASELINE configs[4]
+        # (160 GB of bf16 activations) two cached copies of a step's working set would not fit the 288 GB
+        del keep
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the capture happens on the first batch INSIDE the training loop, while the DataLoader's pin-memory
         # thread may be calling hipHostMalloc / hipEventQuery for the batches it prefetches; in the default "global" mode

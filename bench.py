@@ -137,12 +137,19 @@ def read_profile(L):
     return prof
 
 
-def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, steps, warmup, graph=False, breakdown_steps=0):
+def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, steps, warmup, graph=False, breakdown_steps=0,
+            storage="fp32"):
     """W untimed + K timed training steps of one workload; returns wall time (max over ranks), the HIP-event totals of
     the dominant (stride-1 convolution) kernel family inside the timed steps, and -- from `breakdown_steps` further,
     UNTIMED steps -- the totals of every family.  (Inside the timed region only the dominant family is bracketed: 48
     instead of ~1100 event records per step; measured cost of bracketing everything: 0.3-0.7 % of the step.)"""
+    import gc
+    gc.collect()              # a previous leg's hipGraph (and its private memory pool) dies with its last reference
+    if torch.device(dev).type == "cuda":
+        torch.cuda.empty_cache()
     cfg = make_config(loss_name)
+    if storage != "fp32":     # engine extension: activations and their gradients stored as bf16 (BASELINE configs[4])
+        cfg["model"]["storage_dtype"] = storage
     scale = 2 ** cfg["model"]["num_x2upsample"]
     hr = tuple(v * scale for v in lr_grid)
     torch.manual_seed(42)
@@ -156,6 +163,8 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
         reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
         reducer.broadcast_parameters(opt.flat_param)
     x, b, y = synthetic_batch(batch, hr, scale, 1234 + rank, dev)
+    if torch.device(dev).type == "cuda":
+        torch.cuda.reset_peak_memory_stats(dev)
 
     def step():
         pred = model(x, b)
@@ -218,14 +227,17 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     if on_gpu:
         torch.cuda.empty_cache()
     return {"elapsed": float(t.item()), "prof": prof, "breakdown": breakdown, "breakdown_steps": breakdown_steps,
-            "loss": last_loss, "hr": hr, "cfg": cfg,
+            "loss": last_loss, "hr": hr, "cfg": cfg, "peak_mem_gb": (torch.cuda.max_memory_allocated(dev) / 2 ** 30 if on_gpu else 0.0),
             "voxels_per_step": world * batch * hr[0] * hr[1] * hr[2]}
 
 
-def workload_name(lr_grid, hr, batch, loss_name, world):
+def workload_name(lr_grid, hr, batch, loss_name, world, storage="fp32"):
     cfg_id = {("l1", False): 1, ("mixed", False): 2, ("mixed", True): 3}.get((loss_name, world > 1))
     tag = f" (BASELINE configs[{cfg_id}])" if cfg_id is not None and (batch == (1 if loss_name == "l1" else 4)) else ""
-    return (f"LR {lr_grid[0]}x{lr_grid[1]}x{lr_grid[2]} -> 4x SR HR {hr[0]}x{hr[1]}x{hr[2]}, batch {batch}/GPU, fp32, "
+    if storage != "fp32" or list(lr_grid) != [20, 80, 80]:
+        tag = " (BASELINE configs[4]: per-GPU work)" if (storage == "bf16" and list(lr_grid) == [40, 160, 160] and batch == 1) else ""
+    prec = "fp32" if storage == "fp32" else "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / Adam"
+    return (f"LR {lr_grid[0]}x{lr_grid[1]}x{lr_grid[2]} -> 4x SR HR {hr[0]}x{hr[1]}x{hr[2]}, batch {batch}/GPU, {prec}, "
             f"UNetSR default.yml widths (65.47M params), {'L1' if loss_name == 'l1' else 'MixedDivergenceGradientL2'} "
             f"loss, fwd+loss+bwd{'+RCCL grad all-reduce' if world > 1 else ''}+Adam{tag}")
 
@@ -285,6 +297,21 @@ def main():
             del os.environ["SR3D_SPLIT_F16"]
         else:
             os.environ["SR3D_SPLIT_F16"] = prev
+
+    # bf16 storage (engine extension, BASELINE configs[4]): (a) the headline's own shape, eager, with the kernel breakdown --
+    # like for like with the fp32 line above; (b) configs[4]'s per-GPU workload: LR 40x160x160 -> HR 160x640x640, batch 1,
+    # physics-guided loss, the whole step captured into a hipGraph and replayed
+    bf16_same, bf16_c4 = None, None
+    if not args.no_secondary and not args.graph and not use_dist and os.environ.get("SR3D_BENCH_BF16", "1") != "0":
+        bf16_same = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, min(args.steps, 5), 1,
+                            breakdown_steps=1, storage="bf16")
+        try:
+            bf16_c4 = measure(sr3d_amd, L, dev, rank, world, use_dist, 1, "mixed", [40, 160, 160], min(args.steps, 3), 1,
+                              graph=True, storage="bf16")
+            bf16_c4["mode"] = "hipGraph replay"
+        except torch.cuda.OutOfMemoryError as e:    # report it instead of losing the whole line
+            bf16_c4 = {"error": f"out of memory: {e}"[:300]}
+            torch.cuda.empty_cache()
 
     replay = None      # the same step captured once into a hipGraph and replayed (src/graph.py): no per-launch overhead
     if not args.no_secondary and not args.graph and not use_dist:
@@ -406,6 +433,40 @@ def main():
                                               "GraphedTrainStep and replayed; ~550 launches per step lose ~20 us each on the eager path",
                                       "value": replay["voxels_per_step"] * n5 / replay["elapsed"], "unit": "HR voxels/s",
                                       "steps": n5, "warmup": 2, "ms_per_step": replay["elapsed"] / n5 * 1e3, "loss": replay["loss"]}
+        if bf16_same is not None:
+            n5 = min(args.steps, 5)
+            bp = bf16_same["prof"]["hconv"]
+            balgo = bp["work"] / (bp["ms"] * 1e-3) / 1e12 if bp["ms"] > 0 else 0.0
+            bb = bf16_same["breakdown"]
+            out["bf16_storage"] = {
+                "workload": workload_name(args.lr_grid, bf16_same["hr"], batch, loss_name, world, "bf16"),
+                "note": ("engine extension `model: {storage_dtype: bf16}`: same model, same shape as the headline; NOT the headline "
+                         "(the reference and configs[1] are fp32).  Parity unpinned: the reference has no bf16 path; "
+                         "tests/test_gpu_bf16.py holds every kernel to exactness on bf16-representable operands and the whole "
+                         "model to 3e-2 / 8e-2 (prediction / parameter gradients) of the fp32 oracle"),
+                "value": bf16_same["voxels_per_step"] * n5 / bf16_same["elapsed"], "unit": "HR voxels/s", "steps": n5, "warmup": 1,
+                "ms_per_step": bf16_same["elapsed"] / n5 * 1e3, "loss": bf16_same["loss"], "peak_mem_gb": bf16_same["peak_mem_gb"],
+                "roofline": {"bound": "mfma", "kernel": "hconv_kernel<bf16>: one v_mfma_f32_16x16x32_bf16 per product group "
+                                                        "(executed = algorithmic FLOPs; channel padding to 16 not counted)",
+                             "achieved": balgo, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": balgo / F16_MFMA_PEAK_TFLOPS,
+                             "frac_algorithmic": balgo / F16_MFMA_PEAK_TFLOPS, "executed_per_algorithmic": 1.0,
+                             "kernel_ms_per_step": bp["ms"] / n5, "launches_per_step": bp["launches"] / n5},
+                "conv_kernels": {k: {"ms_per_step": bb[k]["ms"] / bf16_same["breakdown_steps"],
+                                     "algorithmic_tflops": (bb[k]["work"] / (bb[k]["ms"] * 1e-3) / 1e12 if bb[k]["ms"] > 0 else 0.0)}
+                                 for k in ("hconv", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")},
+                "hbm_bound_kernels": {k: {"ms_per_step": bb[k]["ms"] / bf16_same["breakdown_steps"],
+                                          "gbytes_per_s": (bb[k]["work"] / (bb[k]["ms"] * 1e-3) / 1e9 if bb[k]["ms"] > 0 else 0.0)}
+                                      for k in ("loss", "act_bwd", "bias_grad", "adam", "data", "pack_reduce")}}
+        if bf16_c4 is not None:
+            if "error" in bf16_c4:
+                out["config4_bf16_hipgraph"] = bf16_c4
+            else:
+                n3 = min(args.steps, 3)
+                out["config4_bf16_hipgraph"] = {
+                    "workload": workload_name([40, 160, 160], bf16_c4["hr"], 1, "mixed", world, "bf16") + " [hipGraph replay]",
+                    "value": bf16_c4["voxels_per_step"] * n3 / bf16_c4["elapsed"], "unit": "HR voxels/s", "steps": n3, "warmup": 1,
+                    "ms_per_step": bf16_c4["elapsed"] / n3 * 1e3, "loss": bf16_c4["loss"], "peak_mem_gb": bf16_c4["peak_mem_gb"],
+                    "step_algorithmic_tflops": FLOP_PER_VOXEL * bf16_c4["voxels_per_step"] * n3 / bf16_c4["elapsed"] / 1e12}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["cfg"])
         print(json.dumps(out), flush=True)

@@ -9,8 +9,13 @@ mode: "parity unpinned".  What is asserted instead (pytest -m gpu):
    reproduce the fp64 result of the SAME operands up to fp32 accumulation (1e-5 normwise for the fp32 outputs: weight
    and bias gradients) and up to ONE final round-to-nearest-even for the bf16 outputs: compared with the fp64 result
    rounded the same way, at most a stray last-place flip (normwise 2e-4, every element within 1 bf16 ulp).
- * the whole model at default.yml widths against the fp32 ORACLE with a stated tolerance: 3e-2 normwise for the
-   prediction and the loss, 8e-2 for parameter gradients (23 layers each round their output to 8 significand bits).
+ * the whole model (tiny and default.yml widths) against the fp32 ORACLE with a stated tolerance: 1e-2 normwise for the
+   prediction and the loss; 5e-2 for parameter gradients WITH THE BRANCH DECISIONS OF THE bf16 RUN forced into the
+   oracle (oracle/ref_cpu.py:_act, as in tests/test_gpu_default_width.py).  Why forced: 23 layers each round their
+   output to 8 significand bits, which moves ~0.2 % of the pre-activations across the ReLU / LeakyReLU kink; a share p of
+   flipped decisions changes the gradients upstream by ~sqrt(p) per layer (4 %), so the FREE-running gradients of any
+   bf16 evaluation (this one, or AMP on any GPU) sit 10-25 % from the fp32 ones -- that figure is printed and bounded
+   loosely (0.5) as a net for gross errors; the smooth part is what the tolerance is on.
 """
 import json
 
@@ -46,7 +51,9 @@ def q(t):
 def within_one_ulp(got, ref, what):
     got, ref = got.detach().float().cpu().double(), ref.double()
     err = (got - ref).abs()
-    tol = 2.0 ** -7 * ref.abs() + 1e-30
+    # one bf16 ulp of the element, plus the fp32 accumulation noise of the sum behind it (relative to the tensor's scale,
+    # not to an element that happens to cancel to ~0)
+    tol = 2.0 ** -7 * ref.abs() + 1e-5 * float(ref.pow(2).mean().sqrt())
     bad = int((err > tol).sum())
     assert bad == 0, (what, bad, float((err / tol).max()))
     assert relerr(got, ref) < 2e-4, (what, relerr(got, ref))
@@ -186,7 +193,8 @@ def test_bf16_activation_backward_and_bias_gradient_ops(eng):
     dy2 = rep(torch.rand(2, c, 2 * z, 2 * yy, 2 * x, generator=g) - 0.5)
     y2 = rep(torch.rand(2, c, 2 * z, 2 * yy, 2 * x, generator=g) - 0.5)
     dp = torch.empty(2, 8 * c, z, yy, x, dtype=BF, device=DEV)
-    L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy2.to(DEV).to(BF), "dy", BF), L.dev_ptr(y2.to(DEV).to(BF), "y", BF),
+    dy2d, y2d = dy2.to(DEV).to(BF), y2.to(DEV).to(BF)          # (named: a temporary would be freed before the launch)
+    L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy2d, "dy", BF), L.dev_ptr(y2d, "y", BF),
                                            L.dev_ptr(dp, "dp", BF), 2, c, z, yy, x, L.DTYPE_BF16, L.stream_ptr()), "unsh")
     ref = R.shuffle_voxels(torch.where(y2 > 0, dy2, 0.01 * dy2), 2).to(BF).float()
     assert torch.equal(dp.float().cpu(), ref)
@@ -204,39 +212,49 @@ def _bf16_model_vs_oracle(eng, cfg, sd, x, b, y):
     for p in model.parameters():
         assert p.dtype == torch.float32                      # fp32 master weights
     loss_fn = eng.make_loss(cfg)
-    pred = model(x.to(DEV), b.to(DEV))
+    eng.ops.KINK_LOG = []                                    # the branch every fused activation took (test hook)
+    try:
+        pred = model(x.to(DEV), b.to(DEV))
+    finally:
+        kinks, eng.ops.KINK_LOG = eng.ops.KINK_LOG, None
     assert pred.dtype == torch.float32
     loss = loss_fn(pred, y.to(DEV), b.to(DEV))
     loss.backward()
-    rp, rl, _, rg = R.loss_and_grads(sd, cfg, x, b, y)
-    e_pred, e_loss = relerr(pred, rp), abs(float(loss) - float(rl)) / abs(float(rl))
-    e_grad = {k: relerr(p.grad, rg[k]) for k, p in model.named_parameters()}
     assert all(p.grad.dtype == torch.float32 for p in model.parameters())
-    return e_pred, e_loss, e_grad
+    rp, rl, _, rg = R.loss_and_grads(sd, cfg, x, b, y)                       # free-running fp32 oracle
+    fp, fl, _, fg = R.loss_and_grads(sd, cfg, x, b, y, kinks=kinks)          # ... with the bf16 run's decisions
+    res = {"pred": relerr(pred, rp), "loss": abs(float(loss.detach()) - float(rl)) / abs(float(rl)),
+           "pred_forced": relerr(pred, fp),
+           "free": {k: relerr(p.grad, rg[k]) for k, p in model.named_parameters()},
+           "forced": {k: relerr(p.grad, fg[k]) for k, p in model.named_parameters()}}
+    return res
+
+
+def _report_and_check(tag, r):
+    wf, wr = max(r["forced"], key=r["forced"].get), max(r["free"], key=r["free"].get)
+    med = sorted(r["forced"].values())[len(r["forced"]) // 2]
+    print(f"{tag}: pred {r['pred']:.2e}, loss {r['loss']:.2e}; parameter gradients with forced decisions: worst {wf} "
+          f"{r['forced'][wf]:.2e}, median {med:.2e}; free-running: worst {wr} {r['free'][wr]:.2e}")
+    assert r["pred"] < 1e-2 and r["loss"] < 1e-2
+    assert r["forced"][wf] < 5e-2, (wf, r["forced"][wf])
+    assert r["free"][wr] < 0.5, (wr, r["free"][wr])
 
 
 def test_bf16_tiny_model_vs_fp32_oracle(eng):
     d = load_golden("model_tiny_a.npz")
-    e_pred, e_loss, e_grad = _bf16_model_vs_oracle(eng, cfg_of(d), sub(d, "sd"), T(d["x"]), T(d["b"]), T(d["y"]))
-    worst = max(e_grad, key=e_grad.get)
-    print(f"bf16 tiny model vs fp32 oracle: pred {e_pred:.2e}, loss {e_loss:.2e}, worst gradient {worst} {e_grad[worst]:.2e}")
-    assert e_pred < 3e-2 and e_loss < 3e-2 and e_grad[worst] < 8e-2
+    _report_and_check("bf16 tiny model vs fp32 oracle",
+                      _bf16_model_vs_oracle(eng, cfg_of(d), sub(d, "sd"), T(d["x"]), T(d["b"]), T(d["y"])))
 
 
 def test_bf16_default_width_model_vs_fp32_oracle(eng):
     """the whole model at default.yml widths (65.47 M parameters), HR 16x64x64, mixed loss: bf16 storage against the
-    fp32 oracle -- parity unpinned (the reference has no bf16 path); stated tolerance 3e-2 (prediction, loss) / 8e-2
-    (parameter gradients), normwise"""
+    fp32 oracle -- parity unpinned (the reference has no bf16 path); stated tolerances in the module docstring"""
     d = load_golden("model_default_a.npz")
     cfg, meta = cfg_of(d), json.loads(str(d["meta"]))
     torch.manual_seed(meta["seed"])
     sd = {k: v.detach().clone() for k, v in eng.make_model(cfg).state_dict().items()}
     x, b, y = synthetic_inputs(1, tuple(meta["hr"]), meta["s"], meta["seed"] + 1, meta["mask_kind"])
-    e_pred, e_loss, e_grad = _bf16_model_vs_oracle(eng, cfg, sd, x, b, y)
-    worst = max(e_grad, key=e_grad.get)
-    print(f"bf16 default-width model vs fp32 oracle: pred {e_pred:.2e}, loss {e_loss:.2e}, worst gradient {worst} "
-          f"{e_grad[worst]:.2e}, median {sorted(e_grad.values())[len(e_grad) // 2]:.2e}")
-    assert e_pred < 3e-2 and e_loss < 3e-2 and e_grad[worst] < 8e-2
+    _report_and_check("bf16 default-width model vs fp32 oracle", _bf16_model_vs_oracle(eng, cfg, sd, x, b, y))
 
 
 def test_bf16_training_step_with_flat_adam_and_hipgraph(eng):
