@@ -97,7 +97,7 @@ def test_whole_model_default_widths(eng, fname):
     # oracle's pre-activation is within rounding distance of 0.  Asserted: (a) every differing element has
     # |pre-activation| <= KINK_C * eps * (sum_k |w_k| |x_k| + |bias|) of its own dot product (eps = 2^-24; the factor
     # covers the rounding that the inputs accumulated over up to 23 layers), (b) the number of differing decisions is
-    # what that band predicts (<= FLIP_RATE of the elements of any activation, plus a few), not a systematic set.
+    # a handful (<= 4 + FLIP_RATE of the elements of any activation), not a systematic set.
     rec = R.KinkRecorder(audit=True)
     R.unet_forward(sd, cfg["model"], x, b, kinks=rec)
     assert len(rec) == len(kinks) == len(rec.pre) == len(rec.scale) == len(ACT_LAYERS)
@@ -156,8 +156,10 @@ def test_whole_model_default_widths(eng, fname):
 
 
 EPS32 = 2.0 ** -24
-KINK_C = 64.0        # differing decisions must have |pre| <= KINK_C * eps * sum|w||x| (worst observed is printed)
-FLIP_RATE = 2e-5     # expected share of elements inside that band: ~ 2 * KINK_C * eps * sqrt(27 K) * pdf(0) ~ 1e-5
+KINK_C = 8.0         # differing decisions must have |pre| <= KINK_C * eps * sum|w||x| (worst observed: 2.05; a typical
+                     # pre-activation sits at ~3e5 on this scale, so a systematically wrong branch cannot hide here)
+FLIP_RATE = 2e-6     # share of an activation's elements that may differ (observed: 3-13 of 3e7 decisions in the whole
+                     # model, at most 4 in one layer: profiles/r03a_default_width_decision_audit_*.json)
 # the 23 activations in forward order (= order of ops.KINK_LOG and of the oracle's KinkRecorder)
 ACT_LAYERS = (["down%d.convs.%d" % (i, j) for i in (1, 2, 3, 4) for j in (0, 1)] +
               ["latent_layers.0", "latent_layers.2", "latent_layers.4"] +
