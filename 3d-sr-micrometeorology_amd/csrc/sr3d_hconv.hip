@@ -63,7 +63,11 @@ struct HGeo {
   static constexpr int PIECES = NP * 2 * RT;   // 1 KB fragments of one phase: [part][16-row tile]
   static constexpr int WPHASE = PIECES * 1024;
   static constexpr int HB = NP * 2 * HPLANE;   // halo bytes
-  static constexpr size_t LDS = HB + 2 * (size_t)WPHASE;
+  // Weight buffers: the LDS-DMA of a phase is issued NWB - 1 phases before its fragments are read.  The split form has 48
+  // MFMAs (768 cycles) per phase, enough to cover one DMA (issue -> landed 250-400 cycles from L2); the bf16 form has 16
+  // (256 cycles) and was bound by exactly that latency with two buffers (606 TFLOP/s): it runs three phases ahead.
+  static constexpr int NWB = BF ? 4 : 2;
+  static constexpr size_t LDS = HB + NWB * (size_t)WPHASE;
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
@@ -252,8 +256,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const int abase = lane * 16;
 
   // ---- prologue
+  constexpr int NWB = G::NWB, AHEAD = NWB - 1;
   const int nphases = p.nchunks * HPH;
-  dma_w(0, Ws);
+#pragma unroll
+  for (int a = 0; a < AHEAD; a++)
+    if (a < nphases) dma_w(a, Ws + a * G::WPHASE);
   load_raw(0);
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -271,18 +278,20 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
 #pragma unroll   // (rolled, the next chunk's raw rows and their split form are both live in every phase: spills)
     for (int kzy = 0; kzy < HPH; kzy++, phase++) {
-      const unsigned char* W = Ws + (phase & 1) * G::WPHASE + abase;
+      const unsigned char* W = Ws + (phase & (NWB - 1)) * G::WPHASE + abase;
       // Phase 1: this wave's share of the next chunk has landed (issued in phase 0): publish its largest magnitude.
       // Phase 2 (behind the barrier of phase 1): all four maxima -> scale of the next chunk; split its rows.  Both before
       // this phase's DMA is issued: hipcc does not see the hand-written waits and guards the first use of `raw` with its
       // own vmcnt(0).
-      if (HCONV_ABL != 1 && kzy == 1) publish_max((chunk + 1) & 1);
-      if (HCONV_ABL != 1 && kzy == 2) {
+      // (bf16: nothing to publish or scale; the rows are packed in the LAST phase, so that the raw registers and their
+      // packed form are never live together and the loads have the whole chunk to land)
+      if (HCONV_ABL != 1 && !BF && kzy == 1) publish_max((chunk + 1) & 1);
+      if (HCONV_ABL != 1 && kzy == (BF ? AHEAD + 1 : 2)) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         convert(ldexpf(1.f, s_next));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (HCONV_ABL != 2 && phase + 1 < nphases) dma_w(phase + 1, Ws + ((phase + 1) & 1) * G::WPHASE);
+      if (HCONV_ABL != 2 && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + ((phase + AHEAD) & (NWB - 1)) * G::WPHASE);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
       if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
       // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
@@ -316,12 +325,30 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the next phase's weights (issued above, BEFORE the raw rows) have landed; in phase 0 the 8 * HNR raw-row
-      // loads of the next chunk stay in flight
-      if (kzy == 0)
-        asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // The NEXT phase's weights have landed (vector-memory operations complete in issue order).  Younger than their DMA
+      // and allowed to stay in flight: the DMAs of the AHEAD - 1 phases after it, and -- in the first AHEAD phases of a
+      // chunk -- the 8 * HNR raw-row loads of the next chunk, which are issued right after the DMA of phase 0.
+      if constexpr (AHEAD == 1) {
+        if (kzy == 0)
+          asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        static_assert(AHEAD == 1 || (AHEAD == 3 && G::PIECES <= 4), "wait counts below are written for 3 phases ahead, <= 1 DMA per wave and phase");
+        if (phase + AHEAD >= nphases) {            // the last phases: nothing new was issued
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (wave < G::PIECES) {             // this wave issues one DMA per phase: two younger ones
+          if (kzy < AHEAD)
+            asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else {                                   // (32-row blocks: waves 2, 3 issue no weight DMA)
+          if (kzy < AHEAD)
+            asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+      }
       if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
     }
     if (HCONV_ABL != 1 && chunk + 1 < p.nchunks) {

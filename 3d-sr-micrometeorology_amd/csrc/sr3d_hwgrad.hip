@@ -65,10 +65,16 @@ struct HwParams {
   int Npad, Cpad;
   float* slab;               // [S * nseg][27][Npad][Cpad]
   const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
+  int xcd_order;             // consecutive virtual workgroup ids on one XCD (see the kernel)
 };
 
-template <int RT, bool BF>
+// PF: how many steps AHEAD of the usual one the global loads of a row are issued (register ring of PF + 1 pieces).  With
+// PF = 0 a piece is loaded in step t and written to LDS in step t + 1: one step time (~1.3 us of MFMAs at best) must
+// cover the whole HBM / L2 latency of the slowest of the 640 staging threads, and every step ends in a barrier -- the
+// bf16 form of this kernel, with a third of the MFMAs and half the bytes, ran only 16 % faster than the split-f16 form.
+template <int RT, bool BF, int PF>
 __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
+  constexpr int NS = PF + 1;
   using G = WGeo<RT, BF>;
   constexpr int XROW = G::XROW, XBYTES = G::XBYTES;
   constexpr int ESZ = BF ? 2 : 4;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    v = p.xcd_order ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
   }
   const int nb = v % p.nnb;
   v /= p.nnb;
@@ -135,13 +141,20 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
   }
   const bool stager = is_x || (tid - 384) < G::NDY;
   const int xq = x0 + 8 * it_q;
-  float pv[10];   // piece: elements -1 .. 8 (X items use 0..7)
+  float pvr[NS][BF ? 1 : 10];   // piece: elements -1 .. 8 (X items use 0..7); ring of NS pieces in flight
+  u32x4 pqr[NS];                // BF: the 8 bf16 elements of the piece as they are, and its two neighbours
+  unsigned pprevr[NS], pnextr[NS];
 #pragma unroll
-  for (int j = 0; j < 10; j++) pv[j] = 0.f;
-  u32x4 pq = {0u, 0u, 0u, 0u};     // BF: the 8 bf16 elements of the piece as they are, and its two neighbours
-  unsigned pprev = 0u, pnext = 0u;
-  // loads the piece of row (b, z, y) into pv (zeros when the row is outside the grid)
-  auto load_piece = [&](const int b, const int z, const int y) {
+  for (int u = 0; u < NS; u++) {
+#pragma unroll
+    for (int j = 0; j < (BF ? 1 : 10); j++) pvr[u][j] = 0.f;
+    pqr[u] = u32x4{0u, 0u, 0u, 0u}, pprevr[u] = pnextr[u] = 0u;
+  }
+  // loads the piece of row (b, z, y) into ring entry st (zeros when the row is outside the grid)
+  auto load_piece = [&](const int st, const int b, const int z, const int y) {
+    float* pv = pvr[st];
+    u32x4& pq = pqr[st];
+    unsigned &pprev = pprevr[st], &pnext = pnextr[st];
     const bool ok = it_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
     if constexpr (BF) {
       if (ok) {
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       for (int j = 0; j < 10; j++) pv[j] = 0.f;
     }
   };
-  auto split8 = [&](const int off, const float mult, h8& hi, h8& lo) {
+  auto split8 = [&](const float* pv, const int off, const float mult, h8& hi, h8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const float s = pv[off + j] * mult;
@@ -180,8 +193,11 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     }
   };
   // X row (plane slot, y slot) / dY buffer addresses
-  auto write_piece = [&](const int yslot_x, const int dbuf, const float dsign) {
+  auto write_piece = [&](const int st, const int yslot_x, const int dbuf, const float dsign) {
     if (!stager) return;
+    const float* pv = pvr[st];
+    const u32x4 pq = pqr[st];
+    const unsigned pprev = pprevr[st], pnext = pnextr[st];
     if constexpr (BF) {
       if (is_x) {
         *reinterpret_cast<u32x4*>(Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16) = pq;
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     }
     if (is_x) {
       h8 hi, lo;
-      split8(1, mx, hi, lo);
+      split8(pv, 1, mx, hi, lo);
       unsigned char* d = Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16;
       *reinterpret_cast<h8*>(d) = hi;
       *reinterpret_cast<h8*>(d + 32 * PITCH) = lo;
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
 #pragma unroll
       for (int cp = 0; cp < 3; cp++) {   // copy cp holds dY[x' - cp + 1]: element j of the piece = pv[1 + j - cp + 1]
         h8 hi, lo;
-        split8(2 - cp, md * dsign, hi, lo);
+        split8(pv, 2 - cp, md * dsign, hi, lo);
         unsigned char* d = Ds + dbuf * G::DROW + cp * G::DCOPY + it_n * PITCH + it_q * 16;
         *reinterpret_cast<h8*>(d) = hi;
         *reinterpret_cast<h8*>(d + 32 * RT * PITCH) = lo;
@@ -254,16 +270,21 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     const int ya = (int)(r0 - plane * p.Y);
     const long long pend = (plane + 1) * p.Y;
     const int yb = (int)((r1 < pend ? r1 : pend) - plane * p.Y);
-    // step t: write what was loaded in step t-1 (X rows t+2, dY row t+1), load (X rows t+3, dY row t+2), multiply row t
-    for (int t = ya - 4; t < yb; t++) {
+    // step t: write what was loaded in step t - NS (X rows t+2, dY row t+1) from ring entry u, refill that entry with
+    // the rows of step t + NS (X rows t+2+NS, dY row t+1+NS), multiply row t
+    for (int t0 = ya - 3 - NS; t0 < yb; t0 += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      const int t = t0 + u;
+      if (t >= yb) break;
       if (t > ya - 4) {
         const long long rr = plane * p.Y + (t + 1);
-        write_piece((t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
+        write_piece(u, (t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
       }
       if (is_x)
-        load_piece(b, z + it_dz - 1, t + 3);
+        load_piece(u, b, z + it_dz - 1, t + 2 + NS);
       else
-        load_piece(b, z, (t + 2 >= ya && t + 2 < yb) ? t + 2 : -1);
+        load_piece(u, b, z, (t + 1 + NS >= ya && t + 1 + NS < yb) ? t + 1 + NS : -1);
       if (t >= ya) {
         const long long rr = plane * p.Y + t;
         const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
@@ -313,6 +334,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       // they are only needed by write_piece of the next step, where hipcc waits for them itself)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
     }
     r0 = plane * p.Y + yb;
   }
@@ -398,6 +420,24 @@ HwPlan hw_plan(const sr3d_conv_desc_t* d, int n_total, int c_used) {
   return g;
 }
 
+template <bool BF, int PF>
+int hw_launch(int rt, long long nwg, const HwParams& p, hipStream_t st) {
+  constexpr size_t l2 = WGeo<2, BF>::LDS, l1 = WGeo<1, BF>::LDS;
+  static SrPerDevice setup;   // (the attribute is per device, not per thread)
+  if (int rc = setup.once([&]() -> int {
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2, BF, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1, BF, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+        return SR3D_OK;
+      }))
+    return rc;
+  if (rt == 2)
+    hipLaunchKernelGGL((hwgrad_kernel<2, BF, PF>), dim3((unsigned)nwg), dim3(WNT), l2, st, p);
+  else
+    hipLaunchKernelGGL((hwgrad_kernel<1, BF, PF>), dim3((unsigned)nwg), dim3(WNT), l1, st, p);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
 }  // namespace
 
 // slab + 256 bytes for the two maxima
@@ -436,33 +476,22 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   p.nnb = g.nnb, p.ncb = g.ncb, p.nseg = g.nseg, p.S = g.S, p.rows_per_split = g.rows_per_split;
   p.Npad = g.Npad, p.Cpad = g.Cpad;
   p.slab = ws + 64, p.amax = (const float*)amax;
+  // (measured on the level-0/1 layers: +-3 % per layer either way in the split form, 1-5 % faster in the bf16 form)
+  p.xcd_order = getenv("SR3D_HWGRAD_XCD") ? atoi(getenv("SR3D_HWGRAD_XCD")) : (bf ? 1 : 0);
   const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
-  constexpr size_t l2 = WGeo<2>::LDS, l1 = WGeo<1>::LDS, l2b = WGeo<2, true>::LDS, l1b = WGeo<1, true>::LDS;
-  static SrPerDevice setup;   // (the attribute is per device, not per thread)
-  if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2b));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1b));
-        return SR3D_OK;
-      }))
-    return rc;
+  // prefetch distance (see the kernel): SR3D_HWGRAD_PF = 0 | 1 | 2 overrides the default (A/B timing)
+  int pf = bf ? 1 : 0;   // (measured: 0 / 1 / 2 within 1 % of each other in both forms -- the kernel is not latency-bound)
+  if (const char* e = getenv("SR3D_HWGRAD_PF")) pf = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   (void)vox;
   {
     SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
-    if (bf) {
-      if (g.rt == 2)
-        hipLaunchKernelGGL((hwgrad_kernel<2, true>), dim3((unsigned)nwg), dim3(WNT), l2b, st, p);
-      else
-        hipLaunchKernelGGL((hwgrad_kernel<1, true>), dim3((unsigned)nwg), dim3(WNT), l1b, st, p);
-    } else {
-      if (g.rt == 2)
-        hipLaunchKernelGGL((hwgrad_kernel<2, false>), dim3((unsigned)nwg), dim3(WNT), l2, st, p);
-      else
-        hipLaunchKernelGGL((hwgrad_kernel<1, false>), dim3((unsigned)nwg), dim3(WNT), l1, st, p);
-    }
-    SR3D_HIP(hipGetLastError());
+    int rc;
+    if (bf)
+      rc = pf == 0 ? hw_launch<true, 0>(g.rt, nwg, p, st) : (pf == 1 ? hw_launch<true, 1>(g.rt, nwg, p, st) : hw_launch<true, 2>(g.rt, nwg, p, st));
+    else
+      rc = pf == 0 ? hw_launch<false, 0>(g.rt, nwg, p, st) : (pf == 1 ? hw_launch<false, 1>(g.rt, nwg, p, st) : hw_launch<false, 2>(g.rt, nwg, p, st));
+    if (rc) return rc;
   }
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
   const long long total = (long long)n_total * c_used * 27;

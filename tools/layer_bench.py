@@ -46,7 +46,10 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32", help="storage type of the activations")
+    ap.add_argument("--wgrad-only", action="store_true")
     args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     print(f"{'layer':10s} {'Cin':>4s} {'Cout':>5s} s lvl | {'fwd ms':>8s} {'TF':>6s} | {'dgrad ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
@@ -55,7 +58,7 @@ def main():
             continue
         Z, Y, X = [g >> lvl for g in args.grid]
         B = args.batch
-        srcs = [torch.rand(B, c, Z, Y, X, device=dev) - 0.5 for c in cs]
+        srcs = [(torch.rand(B, c, Z, Y, X, device=dev) - 0.5).to(dt) for c in cs]
         need = [c > 5 or (name != "conv0" and c > 1 and not (name == "last" and c == 5)) for c in cs]
         for s, n in zip(srcs, need):
             s.requires_grad_(n)
@@ -72,30 +75,32 @@ def main():
             fwd = lambda: ops.conv3d_act(srcs, wf, bias, act="lrelu", unshuffle=True)  # noqa: E731
         else:
             fwd = lambda: ops.conv3d_act(srcs, wf, None, act="lrelu", stride=stride)  # noqa: E731
-        with torch.no_grad():
-            t_f = timed(fwd, args.iters)
-        y = fwd()
-        gy = torch.rand_like(y)
+        t_f = float("nan")
+        if not args.wgrad_only:
+            with torch.no_grad():
+                t_f = timed(fwd, args.iters)
+        y = gy = None
         # dgrad only / wgrad only through the library entry points
         import ctypes as C
         from sr3d_amd import _lib as L
-        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride)
+        desc = L.conv_desc(B, cin, cout, Z, Y, X, stride, dt)
         if kind == "g":
-            dys = [torch.rand(B, cout, oz, oy, ox, device=dev), torch.rand(B, cout, oz, oy, ox, device=dev)]
+            dys = [torch.rand(B, cout, oz, oy, ox, device=dev).to(dt), torch.rand(B, cout, oz, oy, ox, device=dev).to(dt)]
             wgt = wg
         else:
-            dys = [torch.rand(B, cout, oz, oy, ox, device=dev)]
+            dys = [torch.rand(B, cout, oz, oy, ox, device=dev).to(dt)]
             wgt = None
         det = [s.detach() for s in srcs]
         t_d = float("nan")
         dflops = 0.0
-        if any(need):
+        if any(need) and not args.wgrad_only:
             t_d = timed(lambda: ops._bwd_data(desc, det, need, dys, wf.detach(), None if wgt is None else wgt.detach()), args.iters)
             cneed = sum(c for c, n in zip(cs, need) if n)
             dflops = flops * cneed / cin
         t_w = timed(lambda: ops._bwd_weight(desc, det, dys), args.iters)
-        tot["fwd"][0] += t_f; tot["fwd"][1] += flops
-        if any(need):
+        if not args.wgrad_only:
+            tot["fwd"][0] += t_f; tot["fwd"][1] += flops
+        if any(need) and not args.wgrad_only:
             tot["dgrad"][0] += t_d; tot["dgrad"][1] += dflops
         tot["wgrad"][0] += t_w; tot["wgrad"][1] += flops
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms == ms and ms > 0 else 0.0  # noqa: E731
