@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("SR3D_LIBRARY") or os.path.join(_HERE, "libsr3d.so")
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}
-PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED = 0, 1, 2, 3
+PACK_FWD, PACK_FWD_GATED, PACK_BWD, PACK_BWD_GATED, PACK_FWD_UNSHUFFLE = 0, 1, 2, 3, 4
 ACT_CODE = {None: ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU}
 # indices into the output of sr3d_eval_metrics (include/sr3d.h: SR3D_EVAL_*)
 EVAL_INDEX = {"L1": 0, "L2": 1, "MaskedL1": 2, "MaskedL2": 3, "MaskedL1NearWall": 4, "MaskedL2NearWall": 5,
@@ -45,17 +45,18 @@ SYMBOLS = {
     "sr3d_last_error": (C.c_char_p, []),
     "sr3d_packed_weight_bytes": (_SZ, [_DESC, _I]),
     "sr3d_pack_weights": (_I, [_DESC, _I, _P, _P, _P, _P]),
-    "sr3d_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _I, _I, _P]),
-    "sr3d_gated_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "sr3d_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "sr3d_conv3d_fwd_exports_absmax": (_I, [_DESC, _I]),
+    "sr3d_gated_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "sr3d_conv3d_bwd_data_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_data": (_I, [_DESC, _SL, _I, _P, _P, _SL, _I, _P, _SZ, _P]),
     "sr3d_conv3d_bwd_weight_workspace_bytes": (_SZ, [_DESC, _I]),
-    "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P]),
+    "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P, _P, _P]),
     "sr3d_bias_grad_workspace_bytes": (_SZ, [_I, _I, _LL]),
     "sr3d_bias_grad": (_I, [_P, _I, _I, _LL, _P, _P, _I, _P]),
-    "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _P]),
-    "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _I, _P]),
-    "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _P, _P]),
+    "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _I, _P, _P]),
+    "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sr3d_avgpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sr3d_near_wall": (_I, [_P, _P, _I, _I, _I, _I, _P]),

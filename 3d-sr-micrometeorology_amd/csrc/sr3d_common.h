@@ -97,12 +97,14 @@ struct SrHconvParams {
   float* save_s;
   int TZ_, TY_, TX_;
   int unsh_C, Cg;
+  unsigned* amax_out;  // optional [SR3D_MAX_SRC][64]: max |x| per K-side slice, a by-product of the block scaling (fp32 only)
 };
 int sr3d_hconv_mode();   // SR3D_SPLIT_F16: 0 off, 1 auto (default), 2 always
 // (bf: activations stored as bfloat16, one bf16 MFMA per product; sr3d_conv_desc_t.dtype == SR3D_DTYPE_BF16)
 size_t sr3d_hconv_image_bytes(int rows, int K, bool bf = false);
+// (unsh_C > 0, plain forward only: rows in voxel-unshuffle order -- the image header tells the kernel)
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
-                    const int* cbeg, void* image, bool bf, hipStream_t st);
+                    const int* cbeg, void* image, bool bf, hipStream_t st, int unsh_C = 0);
 int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipStream_t st);
 // split-f16 stride-2 conv over parity classes (sr3d_hconv_s2.hip): mode 1 = forward, mode 2 = input gradient
 struct SrHconvS2Params {
@@ -137,8 +139,9 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
 // split-f16 weight gradient of the stride-1 layers (sr3d_hwgrad.hip); same contract as sr3d_wino_wgrad
 size_t sr3d_hwgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);
 bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy);
+// x_absmax / dy_absmax (optional): [slice][64] maxima exported by the forward kernel / the activation-backward kernels
 int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw, float* ws,
-                hipStream_t st);
+                hipStream_t st, const unsigned* x_absmax = nullptr, const unsigned* dy_absmax = nullptr);
 // Winograd-domain weight gradient (sr3d_wino_wgrad.hip)
 // (the first `c_used` input channels; dW rows keep their full length d->Cin * 27)
 size_t sr3d_wino_wgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used);

@@ -23,11 +23,21 @@ __device__ __forceinline__ float act_slope(float f, int act) {
   return 1.f;
 }
 
+// max |.| of what a thread wrote -> one atomicMax per wave into slot[blockIdx & 63] (bits of a non-negative float order
+// like unsigned integers).  The split-f16 weight gradient needs max |dY| of its operands (sr3d_hwgrad.hip); taking it here,
+// where every element passes through registers anyway, replaces a separate sweep of the tensor.
+__device__ __forceinline__ void export_absmax(float m, unsigned* slots) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slots + (blockIdx.x & 63), __float_as_uint(m));
+}
+
 // d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)        (T: storage type, float or bf16raw; fp32 arithmetic)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ f,
                                                                  const T* __restrict__ s, T* __restrict__ df,
-                                                                 T* __restrict__ dg, long long n, int act) {
+                                                                 T* __restrict__ dg, long long n, int act, unsigned* amax) {
+  float m1 = 0.f, m2 = 0.f;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,20 +48,28 @@ __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __rest
     for (int q = 0; q < 4; q++) {
       o1[q] = a[q] * ss[q] * act_slope(ff[q], act);
       o2[q] = a[q] * ff[q] * (ss[q] * (1.f - ss[q]));
+      m1 = fmaxf(m1, fabsf(o1[q])), m2 = fmaxf(m2, fabsf(o2[q]));
     }
     ActIo<T>::st4(df + 4 * i, o1);
     ActIo<T>::st4(dg + 4 * i, o2);
   }
   for (long long i = n4 * 4 + i0; i < n; i += stride) {
     const float a = ActIo<T>::ld(dy + i), ff = ActIo<T>::ld(f + i), ss = ActIo<T>::ld(s + i);
-    ActIo<T>::st(df + i, a * ss * act_slope(ff, act));
-    ActIo<T>::st(dg + i, a * ff * (ss * (1.f - ss)));
+    const float v1 = a * ss * act_slope(ff, act), v2 = a * ff * (ss * (1.f - ss));
+    m1 = fmaxf(m1, fabsf(v1)), m2 = fmaxf(m2, fabsf(v2));
+    ActIo<T>::st(df + i, v1);
+    ActIo<T>::st(dg + i, v2);
+  }
+  if (amax != nullptr) {
+    export_absmax(m1, amax);
+    export_absmax(m2, amax + 64);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                                             T* __restrict__ dp, long long n) {
+                                                             T* __restrict__ dp, long long n, unsigned* amax) {
+  float m = 0.f;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,11 +77,18 @@ __global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const T* __restrict
     const f32x4 a = ActIo<T>::ld4(dy + 4 * i), yy = ActIo<T>::ld4(y + 4 * i);
     f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; q++) o[q] = yy[q] > 0.f ? a[q] : 0.01f * a[q];
+    for (int q = 0; q < 4; q++) {
+      o[q] = yy[q] > 0.f ? a[q] : 0.01f * a[q];
+      m = fmaxf(m, fabsf(o[q]));
+    }
     ActIo<T>::st4(dp + 4 * i, o);
   }
-  for (long long i = n4 * 4 + i0; i < n; i += stride)
-    ActIo<T>::st(dp + i, ActIo<T>::ld(y + i) > 0.f ? ActIo<T>::ld(dy + i) : 0.01f * ActIo<T>::ld(dy + i));
+  for (long long i = n4 * 4 + i0; i < n; i += stride) {
+    const float v = ActIo<T>::ld(y + i) > 0.f ? ActIo<T>::ld(dy + i) : 0.01f * ActIo<T>::ld(dy + i);
+    m = fmaxf(m, fabsf(v));
+    ActIo<T>::st(dp + i, v);
+  }
+  if (amax != nullptr) export_absmax(m, amax);
 }
 
 // dpre[b][f*C + c][z][y][x] = dy[b][c][2z+fz][2y+fy][2x+fx] * lrelu'(y[same])
@@ -71,7 +96,8 @@ __global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                                        T* __restrict__ dp, int B, int C, int Z,
-                                                                       int Y, int X) {
+                                                                       int Y, int X, unsigned* amax) {
+  float m = 0.f;
   const long long total = (long long)B * C * (2 * Z) * (2 * Y) * X;
   const long long czyx = (long long)Z * Y * X;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -97,9 +123,12 @@ __global__ __launch_bounds__(kThreads) void unshuffle_lrelu_bwd_kernel(const T* 
     const int fz = fz_ & 1, z = fz_ >> 1, fy = fy_ & 1, yy = fy_ >> 1;
     const int f0 = (fz * 2 + fy) * 2;
     const long long o = (((long long)b * 8 * C + (long long)f0 * C + c) * Z + z) * Y * X + (long long)yy * X + x;
-    ActIo<T>::st(dp + o, v.x > 0.f ? g.x : 0.01f * g.x);
-    ActIo<T>::st(dp + o + (long long)C * czyx, v.y > 0.f ? g.y : 0.01f * g.y);
+    const float o0 = v.x > 0.f ? g.x : 0.01f * g.x, o1 = v.y > 0.f ? g.y : 0.01f * g.y;
+    m = fmaxf(m, fmaxf(fabsf(o0), fabsf(o1)));
+    ActIo<T>::st(dp + o, o0);
+    ActIo<T>::st(dp + o + (long long)C * czyx, o1);
   }
+  if (amax != nullptr) export_absmax(m, amax);
 }
 
 // x0[b][c][z][y][x] = c < C ? x[b][c][z/s][y/s][x/s] : mask[b][0][z][y][x]
@@ -380,7 +409,7 @@ extern "C" {
   SR3D_CHECK((dtype) == SR3D_DTYPE_F32 || (dtype) == SR3D_DTYPE_BF16, SR3D_E_ARG, what ": unknown dtype %d", (dtype))
 
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
-                       long long n, int act, int dtype, void* stream) {
+                       long long n, int act, int dtype, void* absmax_out, void* stream) {
   SR3D_DTYPE_CHECK(dtype, "gated_act_bwd");
   SR3D_CHECK(dy && save_f && save_s && d_feat && d_gate && n > 0, SR3D_E_ARG, "gated_act_bwd: bad argument");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_act_bwd: unknown activation %d", act);
@@ -393,16 +422,17 @@ int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, v
   SrProfScope prof(SR3D_PROF_ACT_BWD, 5.0 * esz * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
   if (dtype == SR3D_DTYPE_BF16)
     hipLaunchKernelGGL(gated_act_bwd_kernel<bf16raw>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16raw*)dy, (const bf16raw*)save_f, (const bf16raw*)save_s, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act);
+                       (const bf16raw*)dy, (const bf16raw*)save_f, (const bf16raw*)save_s, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act,
+                       (unsigned*)nullptr);
   else
     hipLaunchKernelGGL(gated_act_bwd_kernel<float>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float*)dy, (const float*)save_f, (const float*)save_s, (float*)d_feat, (float*)d_gate, n,
-                     act);
+                     act, (unsigned*)absmax_out);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 
-int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* stream) {
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* absmax_out, void* stream) {
   SR3D_CHECK(dy && y && dpre && n > 0, SR3D_E_ARG, "lrelu_bwd: bad argument");
   SR3D_DTYPE_CHECK(dtype, "lrelu_bwd");
   SR3D_ALIGN_CHECK(dy, "lrelu_bwd");
@@ -411,16 +441,16 @@ int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int d
   SrProfScope prof(SR3D_PROF_ACT_BWD, (dtype == SR3D_DTYPE_BF16 ? 6.0 : 12.0) * (double)n, (hipStream_t)stream);
   if (dtype == SR3D_DTYPE_BF16)
     hipLaunchKernelGGL(lrelu_bwd_kernel<bf16raw>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, n);
+                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, n, (unsigned*)nullptr);
   else
     hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
-                     (const float*)dy, (const float*)y, (float*)dpre, n);
+                     (const float*)dy, (const float*)y, (float*)dpre, n, (unsigned*)absmax_out);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 
 int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X, int dtype,
-                             void* stream) {
+                             void* absmax_out, void* stream) {
   SR3D_CHECK(dy && y && dpre && B > 0 && C > 0 && Z > 0 && Y > 0 && X > 0, SR3D_E_ARG,
              "unshuffle_lrelu_bwd: bad argument");
   SR3D_DTYPE_CHECK(dtype, "unshuffle_lrelu_bwd");
@@ -430,10 +460,10 @@ int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, i
   SrProfScope prof(SR3D_PROF_ACT_BWD, (dtype == SR3D_DTYPE_BF16 ? 6.0 : 12.0) * 2.0 * (double)total, (hipStream_t)stream);
   if (dtype == SR3D_DTYPE_BF16)
     hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel<bf16raw>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, B, C, Z, Y, X);
+                       (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)dpre, B, C, Z, Y, X, (unsigned*)nullptr);
   else
     hipLaunchKernelGGL(unshuffle_lrelu_bwd_kernel<float>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
-                     (const float*)dy, (const float*)y, (float*)dpre, B, C, Z, Y, X);
+                     (const float*)dy, (const float*)y, (float*)dpre, B, C, Z, Y, X, (unsigned*)absmax_out);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

@@ -170,7 +170,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     }
   };
   // largest |value| among this wave's rows of the chunk in `raw` -> its exchange slot
-  auto publish_max = [&](const int parity) {
+  // per-slice maxima of |x| over this workgroup's halo tiles: exported at the end for the split-f16 weight gradient of the
+  // same layer (sr3d_hwgrad.hip needs max |x| per slice; this kernel sees every element anyway).  Only the workgroups of
+  // the first row block export.  An 8-channel group that straddles a slice boundary counts for both slices: an upper
+  // bound, at most the neighbour's magnitude too large, which costs bits of headroom, never correctness.
+  const bool export_max = !BF && p.amax_out != nullptr && nblk == 0;
+  float rmax0 = 0.f, rmax1 = 0.f, rmax2 = 0.f, rmax3 = 0.f;
+  auto publish_max = [&](const int parity, const int ck) {
     if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
 #pragma unroll
@@ -180,6 +186,14 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) xmax[parity * 4 + wave] = m;
+    if (export_max) {
+      const int gc0 = ck * HKC + sh * 8;
+      const int sa = slice_of(gc0 < p.K ? gc0 : p.K - 1), sb = slice_of(gc0 + 7 < p.K ? gc0 + 7 : p.K - 1);
+      rmax0 = (sa == 0 || sb == 0) ? fmaxf(rmax0, m) : rmax0;
+      rmax1 = (sa == 1 || sb == 1) ? fmaxf(rmax1, m) : rmax1;
+      rmax2 = (sa == 2 || sb == 2) ? fmaxf(rmax2, m) : rmax2;
+      rmax3 = (sa == 3 || sb == 3) ? fmaxf(rmax3, m) : rmax3;
+    }
   };
   // running scale exponent: the largest chunk magnitude seen so far decides (kSplitScaleNone until a non-zero chunk came)
   auto next_scale = [&](const int parity, const int s_run) {
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   for (int a = 0; a < AHEAD; a++)
     if (a < nphases) dma_w(a, Ws + a * G::WPHASE);
   load_raw(0);
-  publish_max(0);
+  publish_max(0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int s_run = next_scale(0, kSplitScaleNone);   // exponent of the scale the accumulators are in
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       // own vmcnt(0).
       // (bf16: nothing to publish or scale; the rows are packed in the LAST phase, so that the raw registers and their
       // packed form are never live together and the loads have the whole chunk to land)
-      if (HCONV_ABL != 1 && !BF && kzy == 1) publish_max((chunk + 1) & 1);
+      if (HCONV_ABL != 1 && !BF && kzy == 1) publish_max((chunk + 1) & 1, chunk + 1);
       if (HCONV_ABL != 1 && kzy == (BF ? AHEAD + 1 : 2)) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         convert(ldexpf(1.f, s_next));
@@ -370,6 +384,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     }
   }
 
+  if (export_max && lane == 0) {   // (bits of a non-negative float order like unsigned integers)
+    unsigned* slot = p.amax_out + ((v / p.nblk) & 63);
+    if (rmax0 > 0.f) atomicMax(slot, __float_as_uint(rmax0));
+    if (rmax1 > 0.f) atomicMax(slot + 64, __float_as_uint(rmax1));
+    if (rmax2 > 0.f) atomicMax(slot + 128, __float_as_uint(rmax2));
+    if (rmax3 > 0.f) atomicMax(slot + 192, __float_as_uint(rmax3));
+  }
   // ------------------------------------------------------------------ epilogue (16 x 16 tiles: column = lane & 15 = voxel,
   // row = 4 (lane >> 4) + register)
   // (sign: the accumulators changed sign nchunks - 1 times)
@@ -404,6 +425,38 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
               }
             }
           }
+      }
+    }
+  } else if (p.epi == SR3D_EPI_UNSHUFFLE && reinterpret_cast<const unsigned*>(p.absmax_w)[1] != 0u) {
+    // Rows in unshuffle order (packed with SR3D_PACK_FWD_UNSHUFFLE): row = c * 8 + f, f = (fz * 2 + fy) * 2 + fx.  A lane's four
+    // registers of a 16-row tile are f = 4 (q & 1) + r of ONE channel: registers (0, 1) and (2, 3) are x-neighbours of
+    // the fine grid -> one 8-byte (bf16: 4-byte) store each, 16 lanes = 128 (64) contiguous bytes.  (In channel order
+    // every value was its own 4-byte store with a stride of 8 bytes, the other half of the line coming from another
+    // workgroup: up1.up.0 forward took 3.4 ms longer than its input gradient.)
+    const int q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int vt = 2 * wave + (j >> 1);
+      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
+      if (oz >= p.Z || oy >= p.Y || ox >= p.X) continue;
+#pragma unroll
+      for (int i = 0; i < NRT; i++) {
+        const int row0 = rblock + i * 16 + 4 * q;      // f = 4 (q & 1) .. + 3
+        const int c = row0 >> 3, fz = q & 1;
+        if (c >= p.unsh_C) continue;
+#pragma unroll
+        for (int fy = 0; fy < 2; fy++) {
+          const int f0 = (fz * 2 + fy) * 2;
+          const float v0 = split_act(acc[i][j][2 * fy] * out_mult + p.bias[f0 * p.unsh_C + c], p.act);
+          const float v1 = split_act(acc[i][j][2 * fy + 1] * out_mult + p.bias[(f0 + 1) * p.unsh_C + c], p.act);
+          const long long o = ((long long)b * p.unsh_C + c) * TZYX + ((long long)(2 * oz + fz) * p.TY_ + (2 * oy + fy)) * p.TX_ + 2 * ox;
+          if constexpr (BF) {
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(p.y) + o) = pk;
+          } else {
+            *reinterpret_cast<float2*>(p.y + o) = float2{v0, v1};
+          }
+        }
       }
     }
   } else if (p.epi == SR3D_EPI_UNSHUFFLE) {
@@ -470,9 +523,11 @@ struct HPackParams {
   const float* w1;
   const float* w2;
   const float* absmax_w;
+  unsigned* hdr;   // image header: [0] max |w| (bits), [1] 1 = rows in voxel-unshuffle order
   _Float16* img;
   int Cout, Cin, kind, K, N, nchunks, nblk, RT, n_off;
   int bf;   // 1: one bf16 part per weight (no scaling) instead of the [hi | lo] fp16 pair
+  int unsh_C;   // > 0: rows in voxel-unshuffle order, GEMM row r = c * 8 + f holds output channel f * unsh_C + c
   int rbeg[SR3D_MAX_SRC + 1];
   int cbeg[SR3D_MAX_SRC];
 };
@@ -482,6 +537,7 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
   const float w_mult = ldexpf(1.f, sw == kSplitScaleNone ? 0 : sw);
   // items of 8 channels: (row block, chunk, 16-row tile, channel half, row, tap 0..27); tap 27 is the zero dummy
   const long long total = (long long)p.nblk * p.nchunks * 28 * p.RT * 64;
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.hdr[1] = p.unsh_C > 0 ? 1u : 0u;   // row order of the image (read by the kernel)
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     // the tap runs fastest over the threads: the 27 taps of one (row, channel) are contiguous in the weight tensor, so a
     // wave's reads are 108-byte runs (with the row fastest every lane read its own 108-byte segment: 4.5 ms per step)
@@ -502,7 +558,9 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     int tapidx = tap;
     if (tap < 27) {
       if (p.kind == SR3D_PACK_FWD) {
-        if (n < p.N) w = p.w1 + (long long)n * p.Cin * 27;
+        // (unshuffle order: the two x-neighbours (f & 1) of an output voxel sit in adjacent accumulator registers)
+        const int nsrc = p.unsh_C > 0 ? (n & 7) * p.unsh_C + (n >> 3) : n;
+        if (n < p.N) w = p.w1 + (long long)nsrc * p.Cin * 27;
       } else if (p.kind == SR3D_PACK_FWD_GATED) {
         const int co = (n >> 6) * 32 + (n & 31);   // 64-row block = 32 feature rows, then the 32 gate rows
         if (co < p.Cout) w = ((n & 32) ? p.w2 : p.w1) + (long long)co * p.Cin * 27;
@@ -585,7 +643,7 @@ size_t sr3d_hconv_image_bytes(int rows, int K, bool bf) {
 }
 
 int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2, const int* rbeg,
-                    const int* cbeg, void* image, bool bf, hipStream_t st) {
+                    const int* cbeg, void* image, bool bf, hipStream_t st, int unsh_C) {
   unsigned* hdr = (unsigned*)image;
   SrProfScope prof(SR3D_PROF_PACK, (bf ? 3.0 : 4.0) * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
@@ -597,6 +655,8 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
   }
   HPackParams p{};
   p.bf = bf ? 1 : 0;
+  p.hdr = hdr, p.unsh_C = unsh_C;
+  SR3D_CHECK(unsh_C == 0 || (kind == SR3D_PACK_FWD && rows == 8 * unsh_C), SR3D_E_ARG, "hconv pack: unshuffle order needs a plain forward image with 8 * C rows");
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.nchunks = ceil_div(K, HKC);
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
@@ -644,6 +704,7 @@ int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipSt
     // region B: its blocks are 32 rows; express the offsets in the kernel's own units
     SrHconvParams q = p;
     q.nblk = 1, q.nb_off = 0;
+    if (n2 > 0) q.amax_out = nullptr;   // (region A's first row block exports the maxima of x)
     q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * HPH * wphase2;
     q.n_off = p.n_off + n2 * 64;
     hipLaunchKernelGGL((hconv_kernel<1, BF>), dim3((unsigned)nsp, B), dim3(HNT), lds1, st, q);

@@ -362,6 +362,23 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     run(std::false_type{});
 }
 
+// amax[i] = max over the 64 hashed slots of slice i, for the slices whose maxima another kernel exported
+// (x: sr3d_hconv.hip forward; dY: the activation-backward kernels) -- instead of a sweep of the tensor
+__global__ __launch_bounds__(64) void hw_gather_amax_kernel(const unsigned* xs, int nx, const unsigned* ds, int nd, unsigned* amax) {
+  const int lane = threadIdx.x;
+  for (int i = 0; i < nx + nd; i++) {
+    const unsigned* src = i < nx ? (xs ? xs + i * 64 : nullptr) : (ds ? ds + (i - nx) * 64 : nullptr);
+    if (src == nullptr) continue;
+    unsigned m = src[lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned t = __shfl_xor(m, o, 64);
+      m = t > m ? t : m;
+    }
+    if (lane == 0) amax[i < nx ? i : 4 + (i - nx)] = m;
+  }
+}
+
 struct HwSliceMap {
   int xcb[SR3D_MAX_SRC], dcb[SR3D_MAX_SRC];   // first channel / row of every slice (INT_MAX: unused)
 };
@@ -456,7 +473,7 @@ bool sr3d_hwgrad_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& 
 }
 
 int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, int c_used, float* dw, float* ws,
-                hipStream_t st) {
+                hipStream_t st, const unsigned* x_absmax, const unsigned* dy_absmax) {
   const HwPlan g = hw_plan(d, n_total, c_used);
   const bool bf = d->dtype == SR3D_DTYPE_BF16;
   unsigned* amax = (unsigned*)ws;
@@ -464,10 +481,14 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   if (!bf) {   // (bf16 operands are not scaled: no maxima pass)
     SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
-    for (int i = 0; i < x.n; i++)
-      if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax + i, st)) return rc;
-    for (int i = 0; i < dy.n; i++)
-      if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 4 + i, st)) return rc;
+    if (x_absmax == nullptr)
+      for (int i = 0; i < x.n; i++)
+        if (int rc = sr3d_absmax_launch(x.ptr[i], (long long)d->B * x.bstride[i], amax + i, st)) return rc;
+    if (dy_absmax == nullptr)
+      for (int i = 0; i < dy.n; i++)
+        if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 4 + i, st)) return rc;
+    if (x_absmax != nullptr || dy_absmax != nullptr)
+      hipLaunchKernelGGL(hw_gather_amax_kernel, dim3(1), dim3(64), 0, st, x_absmax, x.n, dy_absmax, dy.n, amax);
     SR3D_HIP(hipGetLastError());
   }
   HwParams p{};

@@ -739,6 +739,7 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
 extern "C" {
 
 size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
+  if (kind == SR3D_PACK_FWD_UNSHUFFLE) kind = SR3D_PACK_FWD;   // same size, other row order
   if (check_desc(d) != SR3D_OK || (kind != SR3D_PACK_FWD && kind != SR3D_PACK_FWD_GATED)) return 0;
   if (use_smalln_fwd(d, kind)) return (size_t)d->Cin * 108 * 4;
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind))) return sr3d_hconv_image_bytes(hconv_fwd_rows(d, kind), d->Cin, is_bf(d));
@@ -750,6 +751,11 @@ size_t sr3d_packed_weight_bytes(const sr3d_conv_desc_t* d, int kind) {
 int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, const void* w_gate, void* w_packed,
                       void* stream) {
   if (int rc = check_desc(d)) return rc;
+  // SR3D_PACK_FWD_UNSHUFFLE: the image of a layer whose epilogue is the voxel unshuffle.  The split-f16 / bf16 kernel
+  // takes its rows in unshuffle order (paired stores); the other kernels keep channel order.
+  const bool unsh = kind == SR3D_PACK_FWD_UNSHUFFLE;
+  if (unsh) kind = SR3D_PACK_FWD;
+  SR3D_CHECK(!unsh || d->Cout % 8 == 0, SR3D_E_ARG, "pack: unshuffle needs Cout %% 8 == 0 (got %d)", d->Cout);
   SR3D_CHECK(kind == SR3D_PACK_FWD || kind == SR3D_PACK_FWD_GATED, SR3D_E_ARG, "pack: unknown kind %d", kind);
   SR3D_CHECK(w_feat && w_packed, SR3D_E_ARG, "pack: null pointer");
   SR3D_CHECK(kind != SR3D_PACK_FWD_GATED || w_gate, SR3D_E_ARG, "pack: gated kind needs w_gate");
@@ -761,7 +767,7 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   }
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)))
     return sr3d_hconv_pack(kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
-                           (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream);
+                           (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream, unsh ? d->Cout / 8 : 0);
   if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind)))
     return sr3d_hconv_s2_pack(1, kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                               (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream);
@@ -777,8 +783,15 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
   return run_pack(p, fwd_plan(d, p.N, kind == SR3D_PACK_FWD_GATED), (float*)w_packed, (hipStream_t)stream);
 }
 
+int sr3d_conv3d_fwd_exports_absmax(const sr3d_conv_desc_t* d, int gated) {
+  if (check_desc(d) != SR3D_OK || is_bf(d)) return 0;
+  const int kind = gated ? SR3D_PACK_FWD_GATED : SR3D_PACK_FWD;
+  if (use_smalln_fwd(d, kind)) return 0;
+  return use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)) ? 1 : 0;
+}
+
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
-                    const void* bias, void* y, int act, int unshuffle, void* stream) {
+                    const void* bias, void* y, int act, int unshuffle, void* x_absmax, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "conv3d_fwd: null pointer");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "conv3d_fwd: unknown activation %d", act);
@@ -801,6 +814,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     for (int i = 0; i < q.in.n; i++) SR3D_CHECK(q.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
     q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X, q.N = d->Cout;
     q.act = act, q.bias = (const float*)bias;
+    q.amax_out = is_bf(d) ? nullptr : (unsigned*)x_absmax;
     if (unshuffle) {
       SR3D_CHECK(d->Cout % 8 == 0 && bias != nullptr, SR3D_E_ARG,
                  "conv3d_fwd: unshuffle needs Cout %% 8 == 0 and a bias (Cout = %d)", d->Cout);
@@ -855,7 +869,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
 
 int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
                           const void* bias_f, const void* bias_g, void* y, void* save_f, void* save_s, int act,
-                          void* stream) {
+                          void* x_absmax, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "gated_conv3d_fwd: null pointer");
   SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
@@ -870,6 +884,7 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
     q.bias = (const float*)bias_f, q.bias2 = (const float*)bias_g;
     q.y = (float*)y, q.save_f = (float*)save_f, q.save_s = (float*)save_s;
     q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
+    q.amax_out = is_bf(d) ? nullptr : (unsigned*)x_absmax;
     return sr3d_hconv_launch(q, w_packed, d->B, is_bf(d), (hipStream_t)stream);
   }
   if (use_wino(d)) {

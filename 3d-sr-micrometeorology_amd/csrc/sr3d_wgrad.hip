@@ -728,7 +728,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
 
 int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src,
                            const sr3d_slice_t* dy_srcs, int n_dy, void* dw, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           const void* x_absmax, const void* dy_absmax, void* stream) {
   SR3D_CHECK(d && dw && workspace, SR3D_E_ARG, "conv3d_bwd_weight: null pointer");
   SR3D_CHECK(d->stride == 1 || d->stride == 2, SR3D_E_ARG, "conv3d_bwd_weight: stride must be 1 or 2");
   SR3D_CHECK((long long)d->Z * d->Y * d->X < (1ll << 31), SR3D_E_ARG, "conv3d_bwd_weight: grid too large");
@@ -773,7 +773,9 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
       SR3D_CHECK(workspace_bytes >= hwgrad_total_ws(d, n_total), SR3D_E_WORKSPACE,
                  "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
       const int cu = wino_wgrad_c_used(d);
-      if (int rc = sr3d_hwgrad(d, xc, dc, n_total, cu, (float*)dw, (float*)workspace, (hipStream_t)stream)) return rc;
+      if (int rc = sr3d_hwgrad(d, xc, dc, n_total, cu, (float*)dw, (float*)workspace, (hipStream_t)stream,
+                               (const unsigned*)x_absmax, (const unsigned*)dy_absmax))
+        return rc;
       if (cu < d->Cin) {
         float* ws2 = (float*)((char*)workspace + align256(sr3d_hwgrad_ws_bytes(d, n_total, cu)));
         return sr3d_wgrad_few(d, dc, n_total, xc, cu, d->Cin - cu, (float*)dw, (long long)d->Cin * 27, ws2,

@@ -41,18 +41,18 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
-def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of):
+def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of, x_amax=None, dy_amax=None):
     """(dxs, dw, [bias grads]) with the weight-side work on a side stream when the layer's grid is small"""
     vox = desc.Z * desc.Y * desc.X * desc.B
     if not want_w or not any(needs) or vox > CONCURRENT_WGRAD_MAX_VOXELS or L.PROFILING:
         dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
-        dw = _bwd_weight(desc, srcs, dys) if want_w else None
+        dw = _bwd_weight(desc, srcs, dys, x_amax, dy_amax) if want_w else None
         return dxs, dw, [_bias_grad(t) if t is not None else None for t in bias_of]
     cur = torch.cuda.current_stream(dys[0].device)
     side = _side_stream(dys[0].device)
     side.wait_stream(cur)                      # dys / srcs were produced on the current stream
     with torch.cuda.stream(side):
-        dw = _bwd_weight(desc, srcs, dys)
+        dw = _bwd_weight(desc, srcs, dys, x_amax, dy_amax)
         dbs = [_bias_grad(t) if t is not None else None for t in bias_of]
     dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
     cur.wait_stream(side)                      # join: everything returned is ready in current-stream order
@@ -107,7 +107,16 @@ def _bias_grad(dpre: torch.Tensor) -> torch.Tensor:
     return db
 
 
-def _bwd_weight(desc: L.ConvDesc, srcs, dys) -> torch.Tensor:
+def _amax_slots(n: int, like: torch.Tensor) -> torch.Tensor:
+    """zeroed slots for the operand maxima a kernel exports as a by-product (include/sr3d.h: x_absmax / absmax_out)"""
+    return torch.zeros(64 * n, dtype=torch.int32, device=like.device)
+
+
+def _raw_ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _bwd_weight(desc: L.ConvDesc, srcs, dys, x_amax=None, dy_amax=None) -> torch.Tensor:
     n_total = sum(int(d.shape[1]) for d in dys)
     nbytes = L.lib.sr3d_conv3d_bwd_weight_workspace_bytes(C.byref(desc), n_total)
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dys[0].device)
@@ -115,7 +124,7 @@ def _bwd_weight(desc: L.ConvDesc, srcs, dys) -> torch.Tensor:
     dt = L.torch_dtype(desc)
     L.check(L.lib.sr3d_conv3d_bwd_weight(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs),
                                          L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(dw), L.dev_ptr(ws), nbytes,
-                                         L.stream_ptr()), "sr3d_conv3d_bwd_weight")
+                                         _raw_ptr(x_amax), _raw_ptr(dy_amax), L.stream_ptr()), "sr3d_conv3d_bwd_weight")
     return dw
 
 
@@ -150,15 +159,20 @@ class Conv3dAct(torch.autograd.Function):
         weight = weight.contiguous()
         dt = srcs[0].dtype           # storage type of the activations (float32, or bfloat16: model/unet.py storage_dtype)
         desc = L.conv_desc(B, cin, cout, Z, Y, X, stride, dt)
-        wp = pack_weights(desc, L.PACK_FWD, weight, None)
+        wp = pack_weights(desc, L.PACK_FWD_UNSHUFFLE if unshuffle else L.PACK_FWD, weight, None)
         oz, oy, ox = _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride)
         if unshuffle:
             y = _empty((B, cout // 8, 2 * oz, 2 * oy, 2 * ox), srcs[0], dt)
         else:
             y = _empty((B, cout, oz, oy, ox), srcs[0], dt)
+        # max |x| per slice for the weight gradient, where the forward kernel has it as a by-product (fp32, split-f16 kernel)
+        x_amax = None
+        if ctx.needs_input_grad[0] and L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 0):
+            x_amax = _amax_slots(4, srcs[0])
         L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
                                       L.dev_ptr(bias, "bias"), L.dev_ptr(y, "y", dt), L.ACT_CODE[act],
-                                      int(bool(unshuffle)), L.stream_ptr()), "sr3d_conv3d_fwd")
+                                      int(bool(unshuffle)), _raw_ptr(x_amax), L.stream_ptr()), "sr3d_conv3d_fwd")
+        ctx.x_amax = x_amax
         if KINK_LOG is not None and act is not None:
             KINK_LOG.append((y > 0).cpu())
         ctx.desc, ctx.act, ctx.unshuffle, ctx.has_bias, ctx.nsrc = desc, act, unshuffle, bias is not None, len(srcs)
@@ -171,6 +185,8 @@ class Conv3dAct(torch.autograd.Function):
         desc = ctx.desc
         dt = L.torch_dtype(desc)
         dy = dy.to(dt).contiguous()
+        # max |dpre| for the weight gradient comes out of the activation-backward kernel (fp32 only)
+        dy_amax = _amax_slots(1, dy) if (ctx.needs_input_grad[0] and dt == torch.float32 and ctx.act is not None) else None
         if ctx.unshuffle:
             B, c, z2, y2, x2 = dy.shape
             dpre = _empty((B, 8 * c, z2 // 2, y2 // 2, x2 // 2), dy, dt)
@@ -178,11 +194,11 @@ class Conv3dAct(torch.autograd.Function):
                 raise NotImplementedError("unshuffle epilogue is defined with LeakyReLU (unet.py:99-108)")
             L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt),
                                                    L.dev_ptr(dpre, "dpre", dt), B, c, z2 // 2, y2 // 2, x2 // 2,
-                                                   desc.dtype, L.stream_ptr()), "sr3d_unshuffle_lrelu_bwd")
+                                                   desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()), "sr3d_unshuffle_lrelu_bwd")
         elif ctx.act == "lrelu":
             dpre = torch.empty_like(dy)
             L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt), L.dev_ptr(dpre, "dpre", dt),
-                                         dy.numel(), desc.dtype, L.stream_ptr()), "sr3d_lrelu_bwd")
+                                         dy.numel(), desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()), "sr3d_lrelu_bwd")
         elif ctx.act is None:
             dpre = dy
         else:
@@ -190,7 +206,7 @@ class Conv3dAct(torch.autograd.Function):
         needs = ctx.needs_input_grad[5:5 + ctx.nsrc]
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         dxs, dw, (db,) = _grads_two_streams(desc, srcs, needs, [dpre], weight, None, ctx.needs_input_grad[0],
-                                            [dpre if want_b else None])
+                                            [dpre if want_b else None], ctx.x_amax, dy_amax)
         return (dw, db, None, None, None, *dxs)
 
 
@@ -216,11 +232,15 @@ class GatedConv3dAct(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         sf = _empty(oshape, y, dt) if need_bwd else None
         ss = _empty(oshape, y, dt) if need_bwd else None
+        x_amax = None
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 1):
+            x_amax = _amax_slots(4, srcs[0])
         L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
                                             L.dev_ptr(b_feat, "feature bias"), L.dev_ptr(b_gate, "gate bias"),
                                             L.dev_ptr(y, "y", dt), L.dev_ptr(sf, "save_f", dt),
-                                            L.dev_ptr(ss, "save_s", dt), L.ACT_CODE[act], L.stream_ptr()),
-                "sr3d_gated_conv3d_fwd")
+                                            L.dev_ptr(ss, "save_s", dt), L.ACT_CODE[act], _raw_ptr(x_amax),
+                                            L.stream_ptr()), "sr3d_gated_conv3d_fwd")
+        ctx.x_amax = x_amax
         if KINK_LOG is not None and act is not None:
             KINK_LOG.append((sf > 0).cpu())
         ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
@@ -234,14 +254,17 @@ class GatedConv3dAct(torch.autograd.Function):
         dt = L.torch_dtype(desc)
         dy = dy.to(dt).contiguous()
         d_feat, d_gate = torch.empty_like(dy), torch.empty_like(dy)
+        want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dy_amax = _amax_slots(2, dy) if (want_w and dt == torch.float32) else None
         L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(sf, "save_f", dt), L.dev_ptr(ss, "save_s", dt),
                                          L.dev_ptr(d_feat, "d_feat", dt), L.dev_ptr(d_gate, "d_gate", dt), dy.numel(),
-                                         L.ACT_CODE[ctx.act], desc.dtype, L.stream_ptr()), "sr3d_gated_act_bwd")
+                                         L.ACT_CODE[ctx.act], desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()),
+                "sr3d_gated_act_bwd")
         needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
-        want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dxs, dw, (dbf, dbg) = _grads_two_streams(
             desc, srcs, needs, [d_feat, d_gate], w_feat, w_gate, want_w,
-            [d_feat if (ctx.has_bf and ctx.needs_input_grad[2]) else None, d_gate if ctx.needs_input_grad[3] else None])
+            [d_feat if (ctx.has_bf and ctx.needs_input_grad[2]) else None, d_gate if ctx.needs_input_grad[3] else None],
+            ctx.x_amax, dy_amax)
         dwf, dwg = (dw[:desc.Cout], dw[desc.Cout:]) if dw is not None else (None, None)
         return (dwf, dwg, dbf, dbg, None, None, *dxs)
 

@@ -71,7 +71,10 @@ enum {
   SR3D_PACK_FWD = 0,        /* plain conv forward                              */
   SR3D_PACK_FWD_GATED = 1,  /* feature + gate branches interleaved by 32 rows  */
   SR3D_PACK_BWD = 2,        /* transposed image, rows = input channels that need a gradient */
-  SR3D_PACK_BWD_GATED = 3   /* same with K = [d_feat ; d_gate]                 */
+  SR3D_PACK_BWD_GATED = 3,  /* same with K = [d_feat ; d_gate]                 */
+  SR3D_PACK_FWD_UNSHUFFLE = 4 /* plain conv forward of a layer that is called with unshuffle != 0 (UpBlock.up): the
+                                 image may hold its rows in voxel-unshuffle order so that the two x-neighbours of an
+                                 output voxel are stored together; an image packed as SR3D_PACK_FWD works too */
 };
 
 int sr3d_version(void);
@@ -89,13 +92,23 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
  * unshuffle != 0: y is written as unshuffle_voxels(., 2) of that (voxel_shuffle.py:26-42, unet.py:99-108),
  *                 i.e. y has Cout/8 channels on the 2x grid. */
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
-                    const void* bias, void* y, int act, int unshuffle, void* stream);
+                    const void* bias, void* y, int act, int unshuffle, void* x_absmax, void* stream);
+
+/* Operand maxima for the split-f16 weight gradient, without a separate sweep of the tensors.
+ * The split kernels scale their operands by powers of two taken from max |x| and max |dY| per slice.  Kernels that see
+ * every element anyway can export those maxima: `x_absmax` of the two forward calls (optional; 4 x 64 uint32, ZEROED by the
+ * caller; slice i's maximum is the largest of [64 i, 64 i + 64) read as float bits) is filled when
+ * sr3d_conv3d_fwd_exports_absmax() says so for this layer (1: the forward runs on the split-f16 kernel; 0: it does not,
+ * the buffer stays untouched and must not be handed on); `absmax_out` of the three activation-backward calls (64 uint32
+ * per output tensor, zeroed by the caller, fp32 only).  sr3d_conv3d_bwd_weight takes them as `x_absmax` ([n_src][64]) and
+ * `dy_absmax` ([n_dy][64]); NULL = compute by a sweep. */
+int sr3d_conv3d_fwd_exports_absmax(const sr3d_conv_desc_t* d, int gated);
 
 /* y = sigmoid(conv(x;Wg)+bg) * act(conv(x;Wf)[+bf])   custom_conv.py:119-123, 303-304
  * save_f = act(feat), save_s = sigmoid(gate) are kept for the backward pass. */
 int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
                           const void* bias_f, const void* bias_g, void* y, void* save_f, void* save_s, int act,
-                          void* stream);
+                          void* x_absmax, void* stream);
 
 /* ---- backward (autograd of the above: optim_helper.py:165 loss.backward()) -- */
 /* dx_dsts[i] = slice i of d(cat(x)) = conv_transpose(cat(dy_srcs); W)  (aten convolution_backward, input grad)
@@ -113,7 +126,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total);
 int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src,
                            const sr3d_slice_t* dy_srcs, int n_dy, void* dw, void* workspace, size_t workspace_bytes,
-                           void* stream);
+                           const void* x_absmax, const void* dy_absmax, void* stream);
 
 /* db[c] = sum_{b,voxels} dy[b,c,:]   (bias gradient, fp32); workspace >= sr3d_bias_grad_workspace_bytes.
  * `dtype` (here and in the three activation-backward calls below): element type of dy / y / saved tensors / outputs */
@@ -122,13 +135,13 @@ int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, voi
 
 /* d_feat = dy * s * act'(f),  d_gate = dy * f * s * (1 - s)      (autograd of custom_conv.py:119-123) */
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
-                       long long n, int act, int dtype, void* stream);
+                       long long n, int act, int dtype, void* absmax_out /* [2][64]: d_feat, d_gate */, void* stream);
 /* dpre = dy * (y > 0 ? 1 : 0.01)        (autograd of nn.LeakyReLU, y = post-activation) */
-int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* stream);
+int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* absmax_out, void* stream);
 /* dpre(B, 8C, Z, Y, X) = shuffle_voxels(dy * lrelu'(y)) for y, dy of shape (B, C, 2Z, 2Y, 2X)
  * (autograd of unet.py:99-108 up to the conv) */
 int sr3d_unshuffle_lrelu_bwd(const void* dy, const void* y, void* dpre, int B, int C, int Z, int Y, int X, int dtype,
-                             void* stream);
+                             void* absmax_out, void* stream);
 
 /* ---- small data-movement ops ------------------------------------------------ */
 /* x0 = cat[nearest_upsample(x, scale), b]     unet.py:143,254-255 ; x: (B,C,Z/s,Y/s,X/s), b: (B,1,Z,Y,X) */

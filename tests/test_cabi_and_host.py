@@ -42,7 +42,7 @@ def test_argument_errors_are_reported_not_crashes(eng):
     rc = lib.sr3d_pack_weights(C.byref(d), L.PACK_FWD, None, None, None, None)
     assert rc == -1 and b"stride" in lib.sr3d_last_error()
     d = L.conv_desc(1, 4, 8, 8, 8, 8, 1)
-    rc = lib.sr3d_conv3d_fwd(C.byref(d), None, 0, None, None, None, 0, 0, None)
+    rc = lib.sr3d_conv3d_fwd(C.byref(d), None, 0, None, None, None, 0, 0, None, None)
     assert rc == -1 and lib.sr3d_last_error() != b""
     rc = lib.sr3d_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
     assert rc == -1

@@ -186,7 +186,7 @@ def test_bf16_activation_backward_and_bias_gradient_ops(eng):
     dyd, yd = dy.to(DEV).to(BF), y.to(DEV).to(BF)
     out = torch.empty_like(dyd)
     L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dyd, "dy", BF), L.dev_ptr(yd, "y", BF), L.dev_ptr(out, "o", BF), dyd.numel(),
-                                 L.DTYPE_BF16, L.stream_ptr()), "lrelu_bwd")
+                                 L.DTYPE_BF16, None, L.stream_ptr()), "lrelu_bwd")
     assert torch.equal(out.float().cpu(), torch.where(y > 0, dy, 0.01 * dy).to(BF).float())
     # unshuffle backward: (B, C, 2Z, 2Y, 2X) -> (B, 8C, Z, Y, X)
     c, (z, yy, x) = 3, (3, 5, 17)
@@ -195,7 +195,7 @@ def test_bf16_activation_backward_and_bias_gradient_ops(eng):
     dp = torch.empty(2, 8 * c, z, yy, x, dtype=BF, device=DEV)
     dy2d, y2d = dy2.to(DEV).to(BF), y2.to(DEV).to(BF)          # (named: a temporary would be freed before the launch)
     L.check(L.lib.sr3d_unshuffle_lrelu_bwd(L.dev_ptr(dy2d, "dy", BF), L.dev_ptr(y2d, "y", BF),
-                                           L.dev_ptr(dp, "dp", BF), 2, c, z, yy, x, L.DTYPE_BF16, L.stream_ptr()), "unsh")
+                                           L.dev_ptr(dp, "dp", BF), 2, c, z, yy, x, L.DTYPE_BF16, None, L.stream_ptr()), "unsh")
     ref = R.shuffle_voxels(torch.where(y2 > 0, dy2, 0.01 * dy2), 2).to(BF).float()
     assert torch.equal(dp.float().cpu(), ref)
     # bias gradient: fp32 sum of bf16 values

@@ -184,3 +184,44 @@ def test_default_mode_takes_the_split_kernel_only_on_chip_filling_launches(eng, 
             out[mode] = eng.ops.conv3d_act([x], w, None, act=None, stride=1)
     assert torch.equal(out["0"], out["1"])            # 16 workgroups: the Winograd kernel in both
     assert not torch.equal(out["0"], out["2"]) and relerr(out["2"], out["0"]) < 2e-6
+
+
+def test_unshuffle_layer_accepts_both_row_orders_and_exported_maxima_match_a_sweep(eng, forced):
+    """(1) an image packed as SR3D_PACK_FWD (channel order) and one packed as SR3D_PACK_FWD_UNSHUFFLE (rows in voxel-unshuffle
+    order, paired stores) give the same output bit for bit; (2) the weight gradient computed from the maxima that the
+    forward kernel / the activation-backward kernel export equals the one computed from a sweep of the tensors"""
+    import ctypes as C
+    from sr3d_amd import _lib as L
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(2, 33, 5, 7, 40, generator=g) - 0.5).to(DEV)
+    m = (torch.rand(2, 1, 5, 7, 40, generator=g) > 0.3).float().to(DEV)
+    w = (torch.randn(72, 34, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    b = (torch.randn(72, generator=g) * 0.1).to(DEV)
+    desc = L.conv_desc(2, 34, 72, 5, 7, 40, 1)
+    outs = []
+    for kind in (L.PACK_FWD, L.PACK_FWD_UNSHUFFLE):
+        wp = eng.ops.pack_weights(desc, kind, w, None)
+        y = torch.empty(2, 9, 10, 14, 80, device=DEV)
+        L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices([x, m]), 2, L.dev_ptr(wp), L.dev_ptr(b), L.dev_ptr(y), L.ACT_LRELU, 1,
+                                      None, L.stream_ptr()), "fwd")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    # exported maxima: x slices from the forward kernel, dpre from the LeakyReLU backward
+    assert L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 0) == 1
+    xa = torch.zeros(256, dtype=torch.int32, device=DEV)
+    wp = eng.ops.pack_weights(desc, L.PACK_FWD_UNSHUFFLE, w, None)
+    L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices([x, m]), 2, L.dev_ptr(wp), L.dev_ptr(b), L.dev_ptr(y), L.ACT_LRELU, 1,
+                                  C.c_void_p(xa.data_ptr()), L.stream_ptr()), "fwd")
+    got = xa.view(torch.float32).view(4, 64).amax(dim=1).cpu()
+    # upper bounds: at least the true maximum, at most the largest neighbour's (an 8-channel group straddles the slices)
+    assert float(got[0]) == float(x.abs().max()) and float(got[1]) >= 1.0 and float(got[1]) <= max(1.0, float(x.abs().max()))
+    assert float(got[2]) == 0.0 and float(got[3]) == 0.0
+    dy = (torch.rand(2, 72, 5, 7, 40, generator=torch.Generator(device=DEV).manual_seed(1), device=DEV) - 0.5) * 1e-3
+    yy = torch.rand(2, 72, 5, 7, 40, generator=torch.Generator(device=DEV).manual_seed(2), device=DEV) - 0.5
+    dpre, da = torch.empty_like(dy), torch.zeros(64, dtype=torch.int32, device=DEV)
+    L.check(L.lib.sr3d_lrelu_bwd(L.dev_ptr(dy), L.dev_ptr(yy), L.dev_ptr(dpre), dy.numel(), L.DTYPE_F32, C.c_void_p(da.data_ptr()),
+                                 L.stream_ptr()), "lrelu_bwd")
+    assert float(da.view(torch.float32).max()) == float(dpre.abs().max())
+    dw_sweep = eng.ops._bwd_weight(desc, [x, m], [dpre])
+    dw_fused = eng.ops._bwd_weight(desc, [x, m], [dpre], xa, da)
+    assert relerr(dw_fused, dw_sweep) < 2e-6
