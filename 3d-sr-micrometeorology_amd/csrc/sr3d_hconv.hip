@@ -172,8 +172,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   // largest |value| among this wave's rows of the chunk in `raw` -> its exchange slot
   // per-slice maxima of |x| over this workgroup's halo tiles: exported at the end for the split-f16 weight gradient of the
   // same layer (sr3d_hwgrad.hip needs max |x| per slice; this kernel sees every element anyway).  Only the workgroups of
-  // the first row block export.  An 8-channel group that straddles a slice boundary counts for both slices: an upper
-  // bound, at most the neighbour's magnitude too large, which costs bits of headroom, never correctness.
+  // the first row block export.
   const bool export_max = !BF && p.amax_out != nullptr && nblk == 0;
   float rmax0 = 0.f, rmax1 = 0.f, rmax2 = 0.f, rmax3 = 0.f;
   auto publish_max = [&](const int parity, const int ck) {
@@ -189,10 +188,25 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     if (export_max) {
       const int gc0 = ck * HKC + sh * 8;
       const int sa = slice_of(gc0 < p.K ? gc0 : p.K - 1), sb = slice_of(gc0 + 7 < p.K ? gc0 + 7 : p.K - 1);
-      rmax0 = (sa == 0 || sb == 0) ? fmaxf(rmax0, m) : rmax0;
-      rmax1 = (sa == 1 || sb == 1) ? fmaxf(rmax1, m) : rmax1;
-      rmax2 = (sa == 2 || sb == 2) ? fmaxf(rmax2, m) : rmax2;
-      rmax3 = (sa == 3 || sb == 3) ? fmaxf(rmax3, m) : rmax3;
+      auto credit = [&](const int sl, const float mv) {
+        rmax0 = sl == 0 ? fmaxf(rmax0, mv) : rmax0;
+        rmax1 = sl == 1 ? fmaxf(rmax1, mv) : rmax1;
+        rmax2 = sl == 2 ? fmaxf(rmax2, mv) : rmax2;
+        rmax3 = sl == 3 ? fmaxf(rmax3, mv) : rmax3;
+      };
+      if (sa == sb) {
+        credit(sa, m);
+      } else {   // the 8 channels straddle a slice boundary (rare: once or twice per layer): one maximum per channel
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          float mc = 0.f;
+#pragma unroll
+          for (int r = 0; r < HNR; r++) mc = fmaxf(mc, fabsf(raw[r][c]));
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+          credit(slice_of(gc0 + c < p.K ? gc0 + c : p.K - 1), mc);
+        }
+      }
     }
   };
   // running scale exponent: the largest chunk magnitude seen so far decides (kSplitScaleNone until a non-zero chunk came)

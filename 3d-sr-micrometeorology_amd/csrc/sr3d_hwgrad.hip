@@ -457,6 +457,12 @@ int hw_launch(int rt, long long nwg, const HwParams& p, hipStream_t st) {
 
 }  // namespace
 
+int sr3d_gather_absmax(const unsigned* x_absmax, int nx, const unsigned* dy_absmax, int nd, unsigned* amax, hipStream_t st) {
+  hipLaunchKernelGGL(hw_gather_amax_kernel, dim3(1), dim3(64), 0, st, x_absmax, nx, dy_absmax, nd, amax);
+  SR3D_HIP(hipGetLastError());
+  return SR3D_OK;
+}
+
 // slab + 256 bytes for the two maxima
 size_t sr3d_hwgrad_ws_bytes(const sr3d_conv_desc_t* d, int n_total, int c_used) {
   const HwPlan g = hw_plan(d, n_total, c_used);
@@ -488,7 +494,7 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
       for (int i = 0; i < dy.n; i++)
         if (int rc = sr3d_absmax_launch(dy.ptr[i], (long long)d->B * dy.bstride[i], amax + 4 + i, st)) return rc;
     if (x_absmax != nullptr || dy_absmax != nullptr)
-      hipLaunchKernelGGL(hw_gather_amax_kernel, dim3(1), dim3(64), 0, st, x_absmax, x.n, dy_absmax, dy.n, amax);
+      if (int rc = sr3d_gather_absmax(x_absmax, x.n, dy_absmax, dy.n, amax, st)) return rc;
     SR3D_HIP(hipGetLastError());
   }
   HwParams p{};

@@ -570,6 +570,16 @@ inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
   const long long vox = (long long)d->B * d->Z * d->Y * d->X;
   return vox >= 100000 || (n_total >= 1024 && vox >= 16000);
 }
+// ... and the stride-2 layers on its de-interleaving form (sr3d_hwgrad_s2.hip): bf16 always; fp32 where the grid fills the
+// chip (U-Net levels 0-2; SR3D_SPLIT_F16 as above)
+inline bool use_hwgrad_s2(const sr3d_conv_desc_t* d, int n_total) {
+  if (d->stride != 2 || d->X % 16 != 0) return false;
+  if (d->dtype == SR3D_DTYPE_BF16) return true;
+  const int mode = sr3d_hconv_mode();
+  if (mode == 0 || n_total < 16) return false;
+  if (mode == 2) return true;
+  return (long long)d->B * d->Z * d->Y * d->X >= 400000;
+}
 inline size_t hwgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
   const int cu = wino_wgrad_c_used(d);
   size_t bytes = align256(sr3d_hwgrad_ws_bytes(d, n_total, cu));
@@ -723,6 +733,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
   if (use_smalln(d, n_total, 1)) bytes = std::max(bytes, (size_t)smalln_plan(d).S * d->Cin * 108 * 4);
   if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, wino_wgrad_total_ws(d, n_total));
   if (use_hwgrad(d, n_total)) bytes = std::max(bytes, hwgrad_total_ws(d, n_total));
+  if (use_hwgrad_s2(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_s2_ws_bytes(d, n_total));
   return bytes;
 }
 
@@ -762,6 +773,20 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
                        (const float*)workspace, (float*)dw, sp.S, n_total, d->Cin);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
+  }
+  if (use_hwgrad_s2(d, n_total)) {
+    const int OZ = (d->Z - 1) / 2 + 1, OY = (d->Y - 1) / 2 + 1, OX = (d->X - 1) / 2 + 1;
+    ChanCat xc, dc;
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
+    if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)OZ * OY * OX, n_total, &dc, "dy_srcs")) return rc;
+    for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+    if (sr3d_hwgrad_s2_ok(d, xc, dc)) {
+      SR3D_CHECK(workspace_bytes >= sr3d_hwgrad_s2_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
+                 "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+      return sr3d_hwgrad_s2(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream, (const unsigned*)x_absmax,
+                            (const unsigned*)dy_absmax);
+    }
   }
   if (use_hwgrad(d, n_total)) {
     ChanCat xc, dc;

@@ -154,11 +154,12 @@ def test_bf16_gated_conv_forward_and_saved_tensors_exact(eng, cs, cout, grid, st
 
 
 # weight-gradient kernels in bf16 mode: hwgrad_kernel<bf16> (X % 8 == 0) with the few-channel kernel for 1-4 channels
-# beyond a multiple of 32, 32- and 64-row workgroups, two dY slices; the fp32-MFMA direct kernel reading bf16 for
-# X % 8 != 0 and for stride 2
+# beyond a multiple of 32, 32- and 64-row workgroups, two dY slices; hwgrad_s2_kernel<bf16> for stride 2 (X % 16 == 0);
+# the fp32-MFMA direct kernel reading bf16 for the other row lengths
 @pytest.mark.parametrize("cs,n_dy,cout,grid,stride", [
     ([64], 1, 24, (4, 12, 32), 1), ([32, 1, 33], 1, 130, (5, 9, 72), 1), ([64, 2], 2, 36, (3, 26, 40), 1),
     ([40], 1, 64, (5, 7, 20), 1), ([65], 2, 32, (8, 12, 32), 2), ([5], 2, 64, (4, 8, 64), 1), ([64, 5], 1, 4, (4, 8, 32), 1),
+    ([64, 1], 2, 64, (7, 9, 80), 2), ([33], 1, 130, (6, 10, 34), 2),
 ])
 def test_bf16_weight_gradient_kernels_vs_fp64(eng, cs, n_dy, cout, grid, stride):
     from sr3d_amd import _lib as L
