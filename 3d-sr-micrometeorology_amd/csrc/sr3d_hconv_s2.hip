@@ -84,30 +84,37 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
 
   // ---- staging geometry (class-independent part): halo voxel of this lane in round r
+  // Byte offset of this lane's halo voxel inside a channel volume, worked out ONCE: sbase = offset for K-side class
+  // (0, 0, 0), smask bit c = the voxel of class c lies inside the grid.  A load is then one shift, one add, one select.
+  // (The first version recomputed coordinates and range checks for every one of the 8 * HNR loads of every chunk: 12 vector
+  // and 14 scalar instructions per MFMA, matrix pipe 18 % busy -- profiles/r03c_pmc_instruction_mix_down1_0.json.)
   const int sh = wave & 1;
-  int hq[HNR];          // packed (hz, hy, hx) or -1
+  unsigned sbase[HNR], smask[HNR];
   int swr[HNR];
 #pragma unroll
   for (int r = 0; r < HNR; r++) {
     const int e = (r * 2 + (wave >> 1)) * 64 + lane;
     const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
     const int hy = r2 / HHX, hx = r2 - hy * HHX;
-    hq[r] = (hz < UZ && hy < UY && hx < UX) ? (hz << 16 | hy << 8 | hx) : -1;
+    const bool in_halo = hz < UZ && hy < UY && hx < UX;
     swr[r] = e * 16;
-  }
-  // byte offset of that voxel inside a channel volume for K-side class (cz, cy, cx); 0xffffffff = zero
-  auto src_off = [&](const int r, const int cz, const int cy, const int cx) -> unsigned {
-    if (hq[r] < 0) return 0xffffffffu;
-    const int hz = hq[r] >> 16, hy = (hq[r] >> 8) & 255, hx = hq[r] & 255;
-    int gz, gy, gx;
+    unsigned m = 0u;
     if (MODE == 1) {   // sub-volume index q = o0 - 1 + h, input coordinate 2q + class parity
-      gz = 2 * (z0 - 1 + hz) + cz, gy = 2 * (y0 - 1 + hy) + cy, gx = 2 * (x0 - 1 + hx) + cx;
+      const int gz = 2 * (z0 - 1 + hz), gy = 2 * (y0 - 1 + hy), gx = 2 * (x0 - 1 + hx);
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const bool ok = in_halo && (unsigned)(gz + ((c >> 2) & 1)) < (unsigned)p.IZ && (unsigned)(gy + ((c >> 1) & 1)) < (unsigned)p.IY &&
+                        (unsigned)(gx + (c & 1)) < (unsigned)p.IX;
+        m |= ok ? (1u << c) : 0u;
+      }
+      sbase[r] = (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ;   // (wraps for border voxels; used only where a bit is set)
     } else {           // dy coordinate i0 + h
-      gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;
+      const int gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;
+      m = (in_halo && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX) ? 1u : 0u;
+      sbase[r] = (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ;
     }
-    const bool ok = (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;
-    return ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ : 0xffffffffu;
-  };
+    smask[r] = m;
+  }
 
   // per-slice base pointers in scalar registers, mask arithmetic (see sr3d_hconv.hip)
 #define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
@@ -138,14 +145,22 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     const int cc = MODE == 1 ? vc - kc * cpc : vc;
     const bool live = vc < NV;
     const int gc0 = cc * HKC + sh * 8;
+    const unsigned cdelta = (unsigned)((((kc >> 2) & 1) * p.IY + ((kc >> 1) & 1)) * p.IX + (kc & 1)) * (unsigned)ESZ;   // wave-uniform
+    unsigned so_r[HNR];
+#pragma unroll
+    for (int r = 0; r < HNR; r++) so_r[r] = ((smask[r] >> kc) & 1u) ? sbase[r] + cdelta : 0xffffffffu;
+    // channel bases: the usual case is 8 consecutive channels of one tensor
+    const int first = gc0 < p.K ? gc0 : p.K - 1, last = gc0 + 7 < p.K ? gc0 + 7 : p.K - 1;
+    const bool one_slice = ((first >= cb1) + (first >= cb2) + (first >= cb3)) == ((last >= cb1) + (last >= cb2) + (last >= cb3));
+    const unsigned long long b0 = chan_base(first);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       const int gc = gc0 + c;
-      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+      const unsigned long long base = one_slice ? b0 + (unsigned long long)c * (unsigned)chan_bytes : chan_base(gc < p.K ? gc : p.K - 1);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
       for (int r = 0; r < HNR; r++) {
-        const unsigned so = src_off(r, (kc >> 2) & 1, (kc >> 1) & 1, kc & 1);
+        const unsigned so = so_r[r];
         if constexpr (BF)   // the 16 bits of the bf16 element, zero-extended
           raw[r][c] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, so, 0, 0));
         else
