@@ -137,12 +137,12 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   // the tap structure comes from the launch's output class.
   const int cpc = p.nchunks;
   const int NV = MODE == 1 ? 8 * cpc : cpc;
-  auto cls_of = [&](const int vc) { return MODE == 1 ? vc / cpc : ocls; };
+  // (class, chunk-in-class) of a virtual chunk are kept as running counters: no divisions in the loop
 
   float raw[HNR][8];
-  auto load_raw = [&](const int vc) {
-    const int kc = MODE == 1 ? vc / cpc : 0;                       // K-side class (mode 2: dy is not subsampled)
-    const int cc = MODE == 1 ? vc - kc * cpc : vc;
+  auto load_raw = [&](const int vc, const int kc_, const int cc_) {   // kc_: K-side class (mode 1), cc_: 16-channel chunk
+    const int kc = MODE == 1 ? kc_ : 0;                            // (mode 2: dy is not subsampled)
+    const int cc = cc_;
     const bool live = vc < NV;
     const int gc0 = cc * HKC + sh * 8;
     const unsigned cdelta = (unsigned)((((kc >> 2) & 1) * p.IY + ((kc >> 1) & 1)) * p.IX + (kc & 1)) * (unsigned)ESZ;   // wave-uniform
@@ -237,11 +237,12 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   const int abase = lane * 16;
 
   // ---- prologue: weights of the first phase, first chunk staged
-  int cls = cls_of(0);
+  int cls = MODE == 1 ? 0 : ocls;
+  int cc_cur = 0;                               // chunk inside the class (mode 1) / chunk (mode 2)
   int nxp = 1 + (cls & 1);                      // taps of a phase in this chunk's class
   int woff = 0, gph = 0;
   dma_w(0, nxp * NP * RT, Ws);
-  load_raw(0);
+  load_raw(0, 0, 0);
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -251,19 +252,21 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   __builtin_amdgcn_s_barrier();
 
   for (int vc = 0; vc < NV; vc++) {
-    cls = cls_of(vc);
     const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
     const int ny = 1 + py, nph = (1 + pz) * ny;
     nxp = 1 + px;
-    const int cls_n = vc + 1 < NV ? cls_of(vc + 1) : cls;
+    // the next virtual chunk
+    int cc_n = cc_cur + 1, kcls_n = cls;
+    if (MODE == 1 && cc_n == cpc) cc_n = 0, kcls_n = cls + 1;
+    const int cls_n = vc + 1 < NV ? (MODE == 1 ? kcls_n : ocls) : cls;
     for (int ph = 0; ph < nph; ph++, gph++) {
       const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
       const int wsize = nxp * NP * RT * 1024;
       const bool last = ph + 1 == nph;
       if (!(last && vc + 1 == NV)) dma_w(woff + wsize, (last ? 1 + (cls_n & 1) : nxp) * NP * RT, Ws + ((gph + 1) & 1) * G::WBUF);
       __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
-      if (ph == 0) load_raw(vc + 1);
-      const int iz = ph / ny, iy = ph - iz * ny;
+      if (ph == 0) load_raw(vc + 1, kcls_n, cc_n);
+      const int iz = ph >> py, iy = ph & py;     // ph = iz * ny + iy with ny = 1 + py
       const unsigned char* Hk = Hs + ((tap_h(MODE, pz, iz) * HHY + tap_h(MODE, py, iy)) * HHX) * 16;
       h8 fa[2][NP][RT], fb[2][NP][2];   // [tap][part][row tile], [tap][part][voxel row]
 #pragma unroll
@@ -322,6 +325,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    cc_cur = cc_n;
+    if (MODE == 1) cls = kcls_n;
   }
 
   // ------------------------------------------------------------------ epilogue
