@@ -93,3 +93,70 @@ def test_train_loop_with_graph_replay_equals_the_eager_loop(eng):
     l2 = train(loader, m2, lf2, o2, DEV, graph_step=gs)
     assert l1 == l2 and gs.graphed.replays == 3
     assert torch.equal(o1.flat_param, o2.flat_param)
+
+
+def test_capture_while_a_pinning_dataloader_is_producing(eng):
+    """The capture happens on the first batch INSIDE the training loop, while the loader's worker processes and its
+    pin-memory thread keep producing (hipHostMalloc / event queries from another thread).  The capture runs in thread_local
+    error mode, so those calls do not invalidate it; losses equal the eager loop's."""
+    import threading
+    from sr3d_amd.src.optim_helper import LazyGraphedStep
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = cfg_of(d), sub(d, "sd")
+    xs, bs, ys = zip(*[synthetic_inputs(1, (16, 16, 16), 4, 200 + i, "iid") for i in range(48)])
+    ds = torch.utils.data.TensorDataset(torch.cat(xs), torch.cat(bs), torch.cat(ys))
+    stop = threading.Event()
+
+    def churn():     # a second loader whose pin-memory thread is busy for the whole test
+        while not stop.is_set():
+            for batch in torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True):
+                _ = [t.to(DEV, non_blocking=True) for t in batch]
+                if stop.is_set():
+                    break
+
+    th = threading.Thread(target=churn, daemon=True)
+    th.start()
+    try:
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True)
+        m1, lf1, o1 = _setup(eng, cfg, sd, capturable=False)
+        m2, lf2, o2 = _setup(eng, cfg, sd, capturable=True)
+        gs = LazyGraphedStep(m2, lf2, o2)
+        eager, graphed = [], []
+        for i, (x, b, y) in enumerate(loader):
+            if i == 6:
+                break
+            x, b, y = x.to(DEV, non_blocking=True), b.to(DEV, non_blocking=True), y.to(DEV, non_blocking=True)
+            graphed.append(float(gs(x, b, y)))
+            eager.append(_eager(m1, lf1, o1, x, b, y))
+    finally:
+        stop.set()
+        th.join(timeout=60)
+    assert not gs.failed and gs.graphed is not None and gs.graphed.replays == 6
+    assert graphed == eager
+
+
+def test_lazy_graphed_step_falls_back_to_eager_when_the_capture_fails(eng, monkeypatch):
+    from sr3d_amd.src import graph as graph_mod
+    from sr3d_amd.src.optim_helper import LazyGraphedStep
+    d = load_golden("model_tiny_a.npz")
+    cfg, sd = cfg_of(d), sub(d, "sd")
+    batches = [tuple(t.to(DEV) for t in synthetic_inputs(2, (16, 16, 16), 4, 60 + i, "iid")) for i in range(3)]
+    m1, lf1, o1 = _setup(eng, cfg, sd, capturable=False)
+    eager = [_eager(m1, lf1, o1, *bt) for bt in batches]
+
+    class Boom(graph_mod.GraphedTrainStep):
+        def __init__(self, model, loss_fn, optimizer, Xs, bs, ys, warmup=2):
+            for _ in range(2):          # a warm-up that moves the optimizer state, then a failing capture
+                loss = loss_fn(model(Xs, bs), ys, bs)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+            raise RuntimeError("capture invalidated (simulated)")
+
+    monkeypatch.setattr(graph_mod, "GraphedTrainStep", Boom)
+    m2, lf2, o2 = _setup(eng, cfg, sd, capturable=True)
+    gs = LazyGraphedStep(m2, lf2, o2)
+    got = [float(gs(*bt)) for bt in batches]
+    assert gs.failed and gs.graphed is None
+    assert got == eager                                         # state restored, then plain eager steps
+    assert torch.equal(o1.flat_param, o2.flat_param)
