@@ -66,7 +66,6 @@ struct HwParams {
   float* slab;               // [S * nseg][27][Npad][Cpad]
   const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
   int xcd_order;             // consecutive virtual workgroup ids on one XCD (see the kernel)
-  int late_write;            // staging after the step's MFMAs instead of before them
 };
 
 // PF: how many steps AHEAD of the usual one the global loads of a row are issued (register ring of PF + 1 pieces).  With
@@ -278,19 +277,16 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     for (int u = 0; u < NS; u++) {
       const int t = t0 + u;
       if (t >= yb) break;
-      // staging of this step: the rows it writes (X row t+2, dY row t+1) go to slots that row t's products do not read,
-      // so it may run before or AFTER them (late_write: the stagers' conversion work then follows their MFMAs)
-      auto stage = [&]() {
-        if (t > ya - 4) {
-          const long long rr = plane * p.Y + (t + 1);
-          write_piece(u, (t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
-        }
-        if (is_x)
-          load_piece(u, b, z + it_dz - 1, t + 2 + NS);
-        else
-          load_piece(u, b, z, (t + 1 + NS >= ya && t + 1 + NS < yb) ? t + 1 + NS : -1);
-      };
-      if (!p.late_write) stage();
+      // (staging AFTER the step's MFMAs instead of before them -- legal, the rows go to slots row t does not read -- was
+      // tried: no change in the split form, 30 % slower in the bf16 form, profiles/r03d_ab_hwgrad_late_staging.log)
+      if (t > ya - 4) {
+        const long long rr = plane * p.Y + (t + 1);
+        write_piece(u, (t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
+      }
+      if (is_x)
+        load_piece(u, b, z + it_dz - 1, t + 2 + NS);
+      else
+        load_piece(u, b, z, (t + 1 + NS >= ya && t + 1 + NS < yb) ? t + 1 + NS : -1);
       if (t >= ya) {
         const long long rr = plane * p.Y + t;
         const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
@@ -336,7 +332,6 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (p.late_write) stage();
       // (not __syncthreads(): that would drain vmcnt and expose the latency of the loads issued above in every step;
       // they are only needed by write_piece of the next step, where hipcc waits for them itself)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -512,7 +507,6 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   p.slab = ws + 64, p.amax = (const float*)amax;
   // (measured on the level-0/1 layers: +-3 % per layer either way in the split form, 1-5 % faster in the bf16 form)
   p.xcd_order = getenv("SR3D_HWGRAD_XCD") ? atoi(getenv("SR3D_HWGRAD_XCD")) : (bf ? 1 : 0);
-  p.late_write = getenv("SR3D_HWGRAD_LATE") ? atoi(getenv("SR3D_HWGRAD_LATE")) : 0;
   const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
   // prefetch distance (see the kernel): SR3D_HWGRAD_PF = 0 | 1 | 2 overrides the default (A/B timing)

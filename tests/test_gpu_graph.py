@@ -95,6 +95,7 @@ def test_train_loop_with_graph_replay_equals_the_eager_loop(eng):
     assert torch.equal(o1.flat_param, o2.flat_param)
 
 
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
 def test_capture_while_a_pinning_dataloader_is_producing(eng):
     """The capture happens on the first batch INSIDE the training loop, while the loader's worker processes and its
     pin-memory thread keep producing (hipHostMalloc / event queries from another thread).  The capture runs in thread_local
