@@ -73,9 +73,16 @@ static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU
 
 
 
-template <int RT, bool BF>
+// PAIR (bf16 only, even X): the halo is fetched as 4-byte PAIRS of x-neighbours (32 instead of 56 loads per lane and chunk).
+// The bf16 form has a third of the MFMAs per chunk, and with one 2-byte load per voxel and channel the vector-memory
+// instruction rate (~22 cycles per wave instruction, 8 waves per CU) became its limit: a timing-only build WITHOUT the halo
+// refill ran 37 % shorter (profiles/r03d_ablation_hconv_kernel_bf16.log).
+template <int RT, bool BF, bool PAIR>
 __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
+  static_assert(BF || !PAIR, "pair loads are the bf16 path");
   using G = HGeo<RT, BF>;
+  constexpr int NR = PAIR ? 4 : HNR;           // staging rounds
+  constexpr int HPX = 18;                      // PAIR: pairs per halo row, covering hx = -1 .. 34
   constexpr int NP = G::NP;
   constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -111,17 +118,31 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 
   // ---- staging geometry: this wave stages channel half `sh` of every chunk, voxel blocks r * 2 + (wave >> 1)
   const int sh = wave & 1;
-  unsigned soff[HNR];   // byte offset inside a channel volume, 0xffffffff = zero padding
-  int swr[HNR];         // byte offset of the 16-byte piece inside a halo plane
+  unsigned soff[NR];    // byte offset inside a channel volume, 0xffffffff = zero padding
+  int swr[NR];          // byte offset of the 16-byte piece inside a halo plane (PAIR: of the pair's first voxel; < 0: none)
+  int swr2[NR];         // PAIR: of the pair's second voxel (< 0: none)
 #pragma unroll
-  for (int r = 0; r < HNR; r++) {
+  for (int r = 0; r < NR; r++) {
     const int e = (r * 2 + (wave >> 1)) * 64 + lane;
-    const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
-    const int hy = r2 / HHX, hx = r2 - hy * HHX;
-    const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    const bool ok = e < HVOX && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
-    soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * (unsigned)ESZ : 0xffffffffu;
-    swr[r] = e * 16;
+    if constexpr (PAIR) {   // pair pp of row (hz, hy): x = x0 - 2 + 2 pp, + 1  <->  halo columns hx = 2 pp - 1, 2 pp
+      const int hz = e / (HHY * HPX), r2 = e - hz * (HHY * HPX);
+      const int hy = r2 / HPX, pp = r2 - hy * HPX;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 2 + 2 * pp;
+      const bool row = e < HHZ * HHY * HPX;
+      const bool ok = row && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;   // X even: both or none
+      soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 2u : 0xffffffffu;
+      const int v0 = (hz * HHY + hy) * HHX + 2 * pp - 1;
+      swr[r] = (row && pp > 0) ? v0 * 16 : -1;
+      swr2[r] = (row && pp < HPX - 1) ? (v0 + 1) * 16 : -1;
+    } else {
+      const int hz = e / (HHY * HHX), r2 = e - hz * (HHY * HHX);
+      const int hy = r2 / HHX, hx = r2 - hy * HHX;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = e < HVOX && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;
+      soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * (unsigned)ESZ : 0xffffffffu;
+      swr[r] = e * 16;
+      swr2[r] = -1;
+    }
   }
   // Per-slice base pointers of this sample, pinned in scalar registers: left to itself hipcc turns the slice selects into
   // dependent kernel-argument loads (two or three ~200-cycle scalar-load round trips per channel, in every wave, at the
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
     return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
   };
-  float raw[HNR][8];
+  float raw[NR][8];
   auto load_raw = [&](const int chunk) {
     const int gc0 = chunk * HKC + sh * 8;      // wave-uniform
     const int first = gc0 < p.K ? gc0 : p.K - 1, last = gc0 + 7 < p.K ? gc0 + 7 : p.K - 1;
@@ -161,10 +182,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     for (int c = 0; c < 8; c++) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase[c], 0, gc0 + c < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < HNR; r++) {
-        if constexpr (BF)   // the 16 bits of the bf16 element, zero-extended
+      for (int r = 0; r < NR; r++) {
+        if constexpr (BF && !PAIR)   // the 16 bits of the bf16 element, zero-extended
           raw[r][c] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, soff[r], 0, 0));
-        else
+        else                         // fp32 element, or two bf16 x-neighbours
           raw[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[r], 0, 0));
       }
     }
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < HNR; r++)
+    for (int r = 0; r < NR; r++)
 #pragma unroll
       for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
 #pragma unroll
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int c = 0; c < 8; c++) {
           float mc = 0.f;
 #pragma unroll
-          for (int r = 0; r < HNR; r++) mc = fmaxf(mc, fabsf(raw[r][c]));
+          for (int r = 0; r < NR; r++) mc = fmaxf(mc, fabsf(raw[r][c]));
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
           credit(slice_of(gc0 + c < p.K ? gc0 + c : p.K - 1), mc);
@@ -216,10 +237,24 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
   };
-  h8 chi[HNR], clo[HNR];   // halo pieces of the next chunk, split
+  h8 chi[NR], clo[NR];   // halo pieces of the next chunk, split (PAIR: the two voxels of the pair)
   auto convert = [&](const float in_mult) {
 #pragma unroll
-    for (int r = 0; r < HNR; r++) {
+    for (int r = 0; r < NR; r++) {
+      if constexpr (PAIR) {   // dword c = (voxel 0, voxel 1) of channel c  ->  two 16-byte pieces of 8 channels
+        u32x4 p0, p1;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const unsigned a = __builtin_bit_cast(unsigned, raw[r][2 * c]), bq = __builtin_bit_cast(unsigned, raw[r][2 * c + 1]);
+          p0[c] = __builtin_amdgcn_perm(bq, a, 0x05040100u);   // low halves: voxel 0 of channels 2c, 2c + 1
+          p1[c] = __builtin_amdgcn_perm(bq, a, 0x07060302u);   // high halves: voxel 1
+        }
+        chi[r] = __builtin_bit_cast(h8, p0);
+        clo[r] = __builtin_bit_cast(h8, p1);
+        asm volatile("" : "+v"(chi[r]), "+v"(clo[r]));
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if constexpr (BF) {   // pack the 8 channels of a voxel: 16 bytes, the MFMA operand as it is
         u32x4 pk;
 #pragma unroll
@@ -243,7 +278,12 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   };
   auto write_halo = [&]() {
 #pragma unroll
-    for (int r = 0; r < HNR; r++) {
+    for (int r = 0; r < NR; r++) {
+      if constexpr (PAIR) {
+        if (swr[r] >= 0) *reinterpret_cast<h8*>(Hs + sh * HPLANE + swr[r]) = chi[r];
+        if (swr2[r] >= 0) *reinterpret_cast<h8*>(Hs + sh * HPLANE + swr2[r]) = clo[r];
+        continue;
+      }
       if (r == HNR - 1 && swr[r] >= HVOX * 16) continue;   // padding voxels: the exchange slots live there
       *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
       if constexpr (!BF) *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
@@ -366,15 +406,23 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         if (phase + AHEAD >= nphases) {            // the last phases: nothing new was issued
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else if (wave < G::PIECES) {             // this wave issues one DMA per phase: two younger ones
-          if (kzy < AHEAD)
-            asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
-          else
+          if (kzy < AHEAD) {
+            if constexpr (PAIR)
+              asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");   // 2 + 8 * NR
+            else
+              asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
+          } else {
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          }
         } else {                                   // (32-row blocks: waves 2, 3 issue no weight DMA)
-          if (kzy < AHEAD)
-            asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
-          else
+          if (kzy < AHEAD) {
+            if constexpr (PAIR)
+              asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
+          } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          }
         }
       }
       if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
@@ -701,12 +749,12 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
 
 namespace {
 
-template <bool BF>
+template <bool BF, bool PAIR>
 int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipStream_t st) {
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2, BF>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1, BF>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<2, BF, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<2, BF>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hconv_kernel<1, BF, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HGeo<1, BF>::LDS));
         return SR3D_OK;
       }))
     return rc;
@@ -719,7 +767,7 @@ int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipSt
   constexpr size_t wphase2 = HGeo<2, BF>::WPHASE;
   if (n2 > 0) {
     p.nblk = n2, p.nb_off = 0;
-    hipLaunchKernelGGL((hconv_kernel<2, BF>), dim3((unsigned)(nsp * n2), B), dim3(HNT), lds2, st, p);
+    hipLaunchKernelGGL((hconv_kernel<2, BF, PAIR>), dim3((unsigned)(nsp * n2), B), dim3(HNT), lds2, st, p);
   }
   if (n1 > 0) {
     // region B: its blocks are 32 rows; express the offsets in the kernel's own units
@@ -728,7 +776,7 @@ int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipSt
     if (n2 > 0) q.amax_out = nullptr;   // (region A's first row block exports the maxima of x)
     q.wimg = (const unsigned char*)p.wimg + (size_t)n2 * p.nchunks * HPH * wphase2;
     q.n_off = p.n_off + n2 * 64;
-    hipLaunchKernelGGL((hconv_kernel<1, BF>), dim3((unsigned)nsp, B), dim3(HNT), lds1, st, q);
+    hipLaunchKernelGGL((hconv_kernel<1, BF, PAIR>), dim3((unsigned)nsp, B), dim3(HNT), lds1, st, q);
   }
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
@@ -748,5 +796,9 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
   row_split(p.N, &n2, &n1);
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
-  return bf ? hconv_launch_t<true>(p, B, n2, n1, nsp, st) : hconv_launch_t<false>(p, B, n2, n1, nsp, st);
+  if (!bf) return hconv_launch_t<false, false>(p, B, n2, n1, nsp, st);
+  // bf16: pair loads need even rows and 4-byte aligned tensors
+  bool pair = p.X % 2 == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
+  for (int i = 0; i < p.in.n; i++) pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 3) == 0;
+  return pair ? hconv_launch_t<true, true>(p, B, n2, n1, nsp, st) : hconv_launch_t<true, false>(p, B, n2, n1, nsp, st);
 }
