@@ -67,7 +67,12 @@ struct HGeo {
   // MFMAs (768 cycles) per phase, enough to cover one DMA (issue -> landed 250-400 cycles from L2); the bf16 form has 16
   // (256 cycles) and was bound by exactly that latency with two buffers (606 TFLOP/s): it runs three phases ahead.
   static constexpr int NWB = BF ? 4 : 2;
-  static constexpr size_t LDS = HB + NWB * (size_t)WPHASE;
+  // Halo buffers.  bf16: two (2 x 28 KB): the next chunk's halo is written while the current one is multiplied, and the
+  // chunk boundary costs nothing -- with one buffer every chunk ended in "all waves done reading -> write -> barrier ->
+  // first fragment reads", a pipeline drain per 14 x 16 MFMAs (the timing-only build without the refill ran 37 %
+  // shorter, and the loads themselves were only 8 % of that).  The split form's halo is 56 KB: one buffer, two workgroups.
+  static constexpr int HBUF = BF ? 2 : 1;
+  static constexpr size_t LDS = HBUF * (size_t)HB + NWB * (size_t)WPHASE;
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Hs = lds;
-  unsigned char* Ws = lds + G::HB;
+  unsigned char* Ws = lds + G::HBUF * G::HB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,16 +281,17 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       __builtin_amdgcn_sched_barrier(0);               // one round at a time: its temporaries die before the next starts
     }
   };
-  auto write_halo = [&]() {
+  auto write_halo = [&](const int buf) {   // buf: halo buffer (bf16: chunk parity; split form: 0)
+    unsigned char* Hw = Hs + buf * G::HB;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
       if constexpr (PAIR) {
-        if (swr[r] >= 0) *reinterpret_cast<h8*>(Hs + sh * HPLANE + swr[r]) = chi[r];
-        if (swr2[r] >= 0) *reinterpret_cast<h8*>(Hs + sh * HPLANE + swr2[r]) = clo[r];
+        if (swr[r] >= 0) *reinterpret_cast<h8*>(Hw + sh * HPLANE + swr[r]) = chi[r];
+        if (swr2[r] >= 0) *reinterpret_cast<h8*>(Hw + sh * HPLANE + swr2[r]) = clo[r];
         continue;
       }
       if (r == HNR - 1 && swr[r] >= HVOX * 16) continue;   // padding voxels: the exchange slots live there
-      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
+      *reinterpret_cast<h8*>(Hw + (0 * 2 + sh) * HPLANE + swr[r]) = chi[r];
       if constexpr (!BF) *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = clo[r];
     }
   };
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   __builtin_amdgcn_s_barrier();
   int s_run = next_scale(0, kSplitScaleNone);   // exponent of the scale the accumulators are in
   convert(ldexpf(1.f, s_run));
-  write_halo();
+  write_halo(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int s_next = s_run;
@@ -357,13 +363,16 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       if (HCONV_ABL != 1 && kzy == (BF ? AHEAD + 1 : 2)) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         convert(ldexpf(1.f, s_next));
+        // bf16: straight into the OTHER halo buffer (nobody has read it since the previous chunk; the per-phase barriers
+        // that follow publish it long before the next chunk's first fragment read)
+        if constexpr (BF) write_halo((chunk + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (HCONV_ABL != 2 && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + ((phase + AHEAD) & (NWB - 1)) * G::WPHASE);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
       if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
       // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
-      const unsigned char* Hk = Hs + (tap_b ? tap_off(2 * kzy + 1) : tap_off(2 * kzy));
+      const unsigned char* Hk = Hs + (BF ? (chunk & 1) * G::HB : 0) + (tap_b ? tap_off(2 * kzy + 1) : tap_off(2 * kzy));
       h8 fb[NP][4], fa[NP][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
 #pragma unroll
       for (int part = 0; part < NP; part++)
@@ -427,6 +436,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       }
       if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
     }
+    if constexpr (BF) continue;   // (bf16: the halo is double-buffered, the weights keep their sign, nothing to rescale)
     if (HCONV_ABL != 1 && chunk + 1 < p.nchunks) {
       // The f16 MFMA truncates inside its adder tree: every accumulation step leaves a tiny NEGATIVE error whatever the
       // sign of the sum (measured: mean error -5e-7 of the output rms at K = 1032, against 3e-10 for the fp32 MFMA; the
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] *= flip;
       s_run = s_next;
-      write_halo();
+      write_halo(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   // ------------------------------------------------------------------ epilogue (16 x 16 tiles: column = lane & 15 = voxel,
   // row = 4 (lane >> 4) + register)
   // (sign: the accumulators changed sign nchunks - 1 times)
-  const float out_mult = ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
+  const float out_mult = BF ? 1.f : ldexpf((p.nchunks & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
   const int rlane = 4 * (lane >> 4);
@@ -655,7 +665,9 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
           val = w[(long long)k * kstride + tapidx];
         }
       }
-      const float s = val * ((chunk & 1) ? -w_mult : w_mult);   // alternating sign: see the kernel's chunk loop
+      // alternating sign: see the kernel's chunk loop (not in the bf16 form: the truncation bias it cancels, ~5e-7 of the
+      // output's rms, is far below the bf16 rounding of the output)
+      const float s = val * (((chunk & 1) && !p.bf) ? -w_mult : w_mult);
       const _Float16 a = (_Float16)s;
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
