@@ -67,12 +67,19 @@ struct HGeo {
   // MFMAs (768 cycles) per phase, enough to cover one DMA (issue -> landed 250-400 cycles from L2); the bf16 form has 16
   // (256 cycles) and was bound by exactly that latency with two buffers (606 TFLOP/s): it runs three phases ahead.
   static constexpr int NWB = BF ? 4 : 2;
+  // Tap pairs per phase (= per barrier, per weight DMA, per wait).  bf16: TWO -- with 16 MFMAs per phase the ~45 scalar and
+  // ~40 vector bookkeeping instructions of a phase and its barrier were 3 + 2.4 per MFMA and the matrix pipe stood at 35 %
+  // (profiles/r03d_pmc_instruction_mix_up1_bf16.json; weight DMA distance, halo double-buffering and wider halo loads had
+  // each moved it by < 10 %).
+  static constexpr int PP = BF ? 2 : 1;
+  static constexpr int NPH = 14 / PP;          // phases per chunk
+  static constexpr int WPH = PP * WPHASE;      // bytes of one phase's weights = one weight buffer
   // Halo buffers.  bf16: two (2 x 28 KB): the next chunk's halo is written while the current one is multiplied, and the
   // chunk boundary costs nothing -- with one buffer every chunk ended in "all waves done reading -> write -> barrier ->
   // first fragment reads", a pipeline drain per 14 x 16 MFMAs (the timing-only build without the refill ran 37 %
   // shorter, and the loads themselves were only 8 % of that).  The split form's halo is 56 KB: one buffer, two workgroups.
-  static constexpr int HBUF = BF ? 2 : 1;
-  static constexpr size_t LDS = HBUF * (size_t)HB + NWB * (size_t)WPHASE;
+  static constexpr int HBUF = 1;
+  static constexpr size_t LDS = HBUF * (size_t)HB + NWB * (size_t)WPH;
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
 
@@ -301,11 +308,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   // it has just issued.)
   const unsigned char* wblock = reinterpret_cast<const unsigned char*>(p.wimg) + (size_t)(p.nb_off + nblk) * p.nchunks * HPH * G::WPHASE;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wblock, 0, p.nchunks * HPH * G::WPHASE, 0x00020000);
-  auto dma_w = [&](const int phase, unsigned char* W) {   // phase = chunk * 9 + kz * 3 + ky
+  auto dma_w = [&](const int phase, unsigned char* W) {   // phase = chunk * NPH + index of its first tap pair / PP
 #pragma unroll
-    for (int ii = 0; ii < (G::PIECES + 3) / 4; ii++) {
+    for (int ii = 0; ii < (G::PP * G::PIECES + 3) / 4; ii++) {
       const int i = wave + 4 * ii;
-      if (i < G::PIECES) split_lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPHASE + i * 1024 + lane * 16);
+      if (i < G::PP * G::PIECES) split_lds_dma16(wrs, (lds_p)(W + i * 1024), phase * G::WPH + i * 1024 + lane * 16);
     }
   };
 
@@ -331,10 +338,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 
   // ---- prologue
   constexpr int NWB = G::NWB, AHEAD = NWB - 1;
-  const int nphases = p.nchunks * HPH;
+  constexpr int PP = G::PP, NPH = G::NPH;
+  const int nphases = p.nchunks * NPH;
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
-    if (a < nphases) dma_w(a, Ws + a * G::WPHASE);
+    if (a < nphases) dma_w(a, Ws + a * G::WPH);
   load_raw(0);
   publish_max(0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   int phase = 0;
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
 #pragma unroll   // (rolled, the next chunk's raw rows and their split form are both live in every phase: spills)
-    for (int kzy = 0; kzy < HPH; kzy++, phase++) {
-      const unsigned char* W = Ws + (phase & (NWB - 1)) * G::WPHASE + abase;
+    for (int kzy = 0; kzy < NPH; kzy++, phase++) {
+      const unsigned char* W0 = Ws + (phase & (NWB - 1)) * G::WPH + abase;
       // Phase 1: this wave's share of the next chunk has landed (issued in phase 0): publish its largest magnitude.
       // Phase 2 (behind the barrier of phase 1): all four maxima -> scale of the next chunk; split its rows.  Both before
       // this phase's DMA is issued: hipcc does not see the hand-written waits and guards the first use of `raw` with its
@@ -365,14 +373,18 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         convert(ldexpf(1.f, s_next));
         // bf16: straight into the OTHER halo buffer (nobody has read it since the previous chunk; the per-phase barriers
         // that follow publish it long before the next chunk's first fragment read)
-        if constexpr (BF) write_halo((chunk + 1) & 1);
+        if constexpr (BF && G::HBUF == 2) write_halo((chunk + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (HCONV_ABL != 2 && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + ((phase + AHEAD) & (NWB - 1)) * G::WPHASE);
+      if (HCONV_ABL != 2 && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + ((phase + AHEAD) & (NWB - 1)) * G::WPH);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
       if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+#pragma unroll
+      for (int sub = 0; sub < PP; sub++) {
+      const int pair = kzy * PP + sub;
+      const unsigned char* W = W0 + sub * G::WPHASE;
       // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
-      const unsigned char* Hk = Hs + (BF ? (chunk & 1) * G::HB : 0) + (tap_b ? tap_off(2 * kzy + 1) : tap_off(2 * kzy));
+      const unsigned char* Hk = Hs + (G::HBUF == 2 ? (chunk & 1) * G::HB : 0) + (tap_b ? tap_off(2 * pair + 1) : tap_off(2 * pair));
       h8 fb[NP][4], fa[NP][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
 #pragma unroll
       for (int part = 0; part < NP; part++)
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int part = 0; part < NP; part++)
 #pragma unroll
           for (int i = 0; i < 2; i++)
-            if (HCONV_ABL != 4 || (kzy == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
+            if (HCONV_ABL != 4 || (pair == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -402,6 +414,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+      }   // sub
       // The NEXT phase's weights have landed (vector-memory operations complete in issue order).  Younger than their DMA
       // and allowed to stay in flight: the DMAs of the AHEAD - 1 phases after it, and -- in the first AHEAD phases of a
       // chunk -- the 8 * HNR raw-row loads of the next chunk, which are issued right after the DMA of phase 0.
@@ -411,32 +424,25 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         else
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else {
-        static_assert(AHEAD == 1 || (AHEAD == 3 && G::PIECES <= 4), "wait counts below are written for 3 phases ahead, <= 1 DMA per wave and phase");
+        // bf16 form: 3 phases ahead, two tap pairs per phase -> every wave issues ND DMAs per phase (64-row blocks: 8 pieces
+        // over 4 waves; 32-row blocks: 4), so 2 * ND are younger than the one waited for
+        static_assert(AHEAD == 3 && G::PP == 2 && (G::PIECES == 4 || G::PIECES == 2), "wait counts below");
+        constexpr int ND = G::PP * G::PIECES / 4;
         if (phase + AHEAD >= nphases) {            // the last phases: nothing new was issued
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else if (wave < G::PIECES) {             // this wave issues one DMA per phase: two younger ones
-          if (kzy < AHEAD) {
-            if constexpr (PAIR)
-              asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");   // 2 + 8 * NR
-            else
-              asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-          }
-        } else {                                   // (32-row blocks: waves 2, 3 issue no weight DMA)
-          if (kzy < AHEAD) {
-            if constexpr (PAIR)
-              asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
-            else
-              asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          }
+        } else if (kzy < AHEAD) {                  // + the 8 * NR raw-row loads of the next chunk
+          if constexpr (ND == 2 && PAIR) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+          if constexpr (ND == 2 && !PAIR) asm volatile("s_waitcnt vmcnt(60) lgkmcnt(0)" ::: "memory");
+          if constexpr (ND == 1 && PAIR) asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");
+          if constexpr (ND == 1 && !PAIR) asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
+        } else {
+          if constexpr (ND == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          if constexpr (ND == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         }
       }
       if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
     }
-    if constexpr (BF) continue;   // (bf16: the halo is double-buffered, the weights keep their sign, nothing to rescale)
+    if constexpr (G::HBUF == 2) continue;   // (double-buffered halo: written during the chunk)
     if (HCONV_ABL != 1 && chunk + 1 < p.nchunks) {
       // The f16 MFMA truncates inside its adder tree: every accumulation step leaves a tiny NEGATIVE error whatever the
       // sign of the sum (measured: mean error -5e-7 of the output rms at K = 1032, against 3e-10 for the fp32 MFMA; the
@@ -444,11 +450,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       // 5e-5 off).  So the packed weights alternate sign from chunk to chunk and the accumulators are negated in
       // between: the result is unchanged and the truncation errors of successive chunks cancel.  (The same multiply
       // moves the accumulators to the next chunk's scale when that chunk is larger than everything before it.)
-      const float flip = -ldexpf(1.f, s_next - s_run);
+      if constexpr (!BF) {   // (bf16: the weights keep their sign, nothing to rescale)
+        const float flip = -ldexpf(1.f, s_next - s_run);
 #pragma unroll
-      for (int i = 0; i < NRT; i++)
+        for (int i = 0; i < NRT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] *= flip;
+          for (int j = 0; j < 4; j++) acc[i][j] *= flip;
+      }
       s_run = s_next;
       write_halo(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32", help="storage type of the activations")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default=os.environ.get("SR3D_LAYER_DTYPE", "fp32"), help="storage type of the activations")
     ap.add_argument("--wgrad-only", action="store_true")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
