@@ -14,7 +14,7 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["gradnorm", "hipgraph"])
+@pytest.mark.parametrize("variant", ["gradnorm", "hipgraph", "bf16_hipgraph"])
 def test_train_script_single_gpu(tmp_path, variant):
     data_root = write_synthetic_tree(tmp_path / "d", HR=(16, 32, 32), days=6)
     cfg = {
@@ -33,9 +33,11 @@ def test_train_script_single_gpu(tmp_path, variant):
                   "conv_mode_feat_extraction": "g_conv_with_separated_bias",
                   "conv_mode_down_block": "g_conv_with_separated_bias", "conv_mode_up_block": None},
     }
-    if variant == "hipgraph":      # engine extension: the step as a hipGraph replay (no GradNorm: it has its own optimizer)
+    if variant in ("hipgraph", "bf16_hipgraph"):      # engine extension: the step as a hipGraph replay (no GradNorm: it has its own optimizer)
         del cfg["train"]["grad_norm"]
         cfg["train"]["hip_graph"] = True
+    if variant == "bf16_hipgraph":                    # engine extension: bf16 storage inside the network (BASELINE configs[4])
+        cfg["model"]["storage_dtype"] = "bf16"
     (tmp_path / "exp").mkdir()
     cfg_path = tmp_path / "exp" / "tiny.yml"
     cfg_path.write_text(yaml.safe_dump(cfg))
