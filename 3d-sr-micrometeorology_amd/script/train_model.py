@@ -59,7 +59,7 @@ class _Both:
 
 
 def train_and_validate(rank: int, world_size: int, config: dict, weight_path: str, learning_history_path: str,
-                       data_root: str, port: int):
+                       data_root: str, port):
     import sr3d_amd
     from sr3d_amd.src.dataloader import data_dirs_of_config, make_dataloaders, split_into_train_valid_test_dirs
     from sr3d_amd.src.gradnorm import GradNorm
@@ -70,7 +70,13 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
     if rank == 0:
         logging.basicConfig(level=logging.INFO, handlers=[
             logging.StreamHandler(sys.stdout), logging.FileHandler(os.path.join(os.path.dirname(weight_path), "log.txt"))])
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    # rendezvous: a file next to the results (no TCP port to race for between `_free_port()` and the workers' bind: an
+    # "address already in use" was seen once in a test run); an int is still taken as a TCP port on 127.0.0.1
+    if isinstance(port, int):
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        init_method = None
+    else:
+        init_method = f"file://{port}"
     # RCCL ("nccl" under PyTorch-ROCm), one GPU per rank.  SR3D_DIST_BACKEND=gloo keeps the ranks on the CPU: the
     # multi-process rehearsal of this function's control flow (tests/test_dist_paths_gloo.py, with a stub engine -- the
     # HIP engine itself has no CPU path and raises).
@@ -78,10 +84,10 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
     if backend == "nccl":
         device = torch.device("cuda", rank)
         torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+        dist.init_process_group("nccl", init_method=init_method, rank=rank, world_size=world_size, device_id=device)
     else:
         device = torch.device("cpu")
-        dist.init_process_group(backend, rank=rank, world_size=world_size)
+        dist.init_process_group(backend, init_method=init_method, rank=rank, world_size=world_size)
     set_seeds(config["train"]["seed"])
     use_grad_norm = "grad_norm" in config["train"]
 
@@ -207,8 +213,13 @@ def main():
         mlflow = None
     try:
         t0 = time.time()
+        rendezvous = os.path.join(result_dir, ".rendezvous")
+        if os.path.exists(rendezvous):
+            os.remove(rendezvous)
         mp.spawn(train_and_validate, args=(args.world_size, config, weight_path, history_path, args.data_root,
-                                           _free_port()), nprocs=args.world_size, join=True)
+                                           rendezvous), nprocs=args.world_size, join=True)
+        if os.path.exists(rendezvous):
+            os.remove(rendezvous)
         logger.info(f"Total elapsed time = {time.time() - t0} sec")
 
         # final evaluation on the test split (train_model.py:351-390): whole domain, the reference's ten metrics

@@ -145,8 +145,8 @@ def test_train_and_validate_two_ranks_gloo(tmp_path, variant):
     (res / "config.yml").write_text(yaml.safe_dump(config))
     weight_path, history_path = str(res / "weights.pth"), str(res / "learning_history.csv")
     world = 2
-    mp.spawn(_train_worker, args=(world, config, weight_path, history_path, str(data_root), _free_port()),
-             nprocs=world, join=True)      # raises if a rank fails or hangs up
+    mp.spawn(_train_worker, args=(world, config, weight_path, history_path, str(data_root), str(res / ".rendezvous")),
+             nprocs=world, join=True)      # raises if a rank fails or hangs up (file rendezvous, as train_model.main uses)
     sd = torch.load(weight_path)
     assert set(sd) == {"body.weight", "body.bias", "last.weight", "last.bias"}
     hist = open(history_path).read().strip().splitlines()
