@@ -100,6 +100,7 @@ def test_capture_while_a_pinning_dataloader_is_producing(eng):
     """The capture happens on the first batch INSIDE the training loop, while the loader's worker processes and its
     pin-memory thread keep producing (hipHostMalloc / event queries from another thread).  The capture runs in thread_local
     error mode, so those calls do not invalidate it; losses equal the eager loop's."""
+    import faulthandler
     import threading
     from sr3d_amd.src.optim_helper import LazyGraphedStep
     d = load_golden("model_tiny_a.npz")
@@ -107,23 +108,33 @@ def test_capture_while_a_pinning_dataloader_is_producing(eng):
     xs, bs, ys = zip(*[synthetic_inputs(1, (16, 16, 16), 4, 200 + i, "iid") for i in range(48)])
     ds = torch.utils.data.TensorDataset(torch.cat(xs), torch.cat(bs), torch.cat(ys))
     stop = threading.Event()
+    # Worker processes are forked HERE, from the main thread, before the second thread exists: forking from a thread
+    # while another one is inside the HIP runtime can hand a child a locked mutex (a hang of the test's own making).
+    # `timeout` turns a starved loader into an error instead of a silent wait.
+    churn_loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True,
+                                               persistent_workers=True, timeout=120)
+    churn_it = iter(churn_loader)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True, timeout=120)
+    loader_it = iter(loader)
 
     def churn():     # a second loader whose pin-memory thread is busy for the whole test
+        it = churn_it
         while not stop.is_set():
-            for batch in torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True):
+            for batch in it:
                 _ = [t.to(DEV, non_blocking=True) for t in batch]
                 if stop.is_set():
-                    break
+                    return
+            it = iter(churn_loader)          # persistent workers: no new fork
 
+    faulthandler.dump_traceback_later(240, exit=False)      # a hang leaves every thread's stack in the log
     th = threading.Thread(target=churn, daemon=True)
     th.start()
     try:
-        loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2, pin_memory=True)
         m1, lf1, o1 = _setup(eng, cfg, sd, capturable=False)
         m2, lf2, o2 = _setup(eng, cfg, sd, capturable=True)
         gs = LazyGraphedStep(m2, lf2, o2)
         eager, graphed = [], []
-        for i, (x, b, y) in enumerate(loader):
+        for i, (x, b, y) in enumerate(loader_it):
             if i == 6:
                 break
             x, b, y = x.to(DEV, non_blocking=True), b.to(DEV, non_blocking=True), y.to(DEV, non_blocking=True)
@@ -132,6 +143,8 @@ def test_capture_while_a_pinning_dataloader_is_producing(eng):
     finally:
         stop.set()
         th.join(timeout=60)
+        faulthandler.cancel_dump_traceback_later()
+        del loader_it, churn_it
     assert not gs.failed and gs.graphed is not None and gs.graphed.replays == 6
     assert graphed == eager
 

@@ -3,6 +3,9 @@
 //   mode 1  "3 x bf16": 6 bf16 MFMAs 32x32x16 per 16 k-values (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
 //   mode 2  "2 x f16":  3 f16 MFMAs 32x32x16 per 16 k-values (hi*hi, hi*lo, lo*hi) -- the scheme of csrc/sr3d_hconv.hip
 //   mode 3  the same products as 16x16x32 MFMAs (4 accumulator registers per tile, K = 32)
+//   mode 4  the SAME NUMBER of MFMA instructions as mode 3, but the CDNA3-era v_mfma_f32_16x16x16_f16 (K = 16): if it issued
+//           at twice the cadence it would be the natural instruction for the odd 27th tap of sr3d_hconv.hip (27 taps = 13
+//           K = 32 pairs + one K = 16 single instead of a zero-padded 14th pair); it does not -- see the printed times
 // Each mode runs for tens of milliseconds with lane-dependent operands (power management reacts within milliseconds;
 // a 2 ms burst with constant operands overstates the sustained rate) and reports the shader clock it saw
 // (s_memtime cycles per s_memrealtime tick of 100 MHz).  Build and run:
@@ -57,6 +60,16 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
       for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(k + i) & 3], bh[(k ^ i) & 3], acc[i], 0, 0, 0);
+    } else if (MODE == 4) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const h4 a4 = {ah[(k + i) & 3][0], ah[(k + i) & 3][1], ah[(k + i) & 3][2], ah[(k + i) & 3][3]};
+          const h4 b4 = {bh[(k ^ i) & 3][0], bh[(k ^ i) & 3][1], bh[(k ^ i) & 3][2], bh[(k ^ i) & 3][3]};
+          acc4[(2 * i + k) & 15] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc4[(2 * i + k) & 15], 0, 0, 0);
+        }
     } else {
       // the same FLOPs per iteration: 4 accumulators x 32x32x16 = 16 tiles of 16x16; per tile 3 products x (K = 16 -> half
       // an MFMA of K = 32): 24 MFMAs 16x16x32 per iteration
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
         for (int i = 0; i < 8; i++) acc4[(2 * i + k) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[(k + i) & 3], bh[(k ^ i) & 3], acc4[(2 * i + k) & 15], 0, 0, 0);
     }
   }
-  if (MODE == 3) {
+  if (MODE >= 3) {
 #pragma unroll
     for (int i = 0; i < 16; i++)
 #pragma unroll
@@ -107,7 +120,7 @@ int main() {
   unsigned long long* clk;
   hipMalloc(&out, 256 * 2 * 256 * sizeof(float));
   hipMalloc(&clk, 512 * 2 * sizeof(unsigned long long));
-  double mhz[4], ms[4];
+  double mhz[5], ms[5];
   const double t0 = run<0>(out, clk, 40000, &mhz[0], &ms[0]);
   const double t1 = run<1>(out, clk, 100000, &mhz[1], &ms[1]);
   const double t2 = run<2>(out, clk, 200000, &mhz[2], &ms[2]);
@@ -116,5 +129,8 @@ int main() {
   printf("3 x bf16 (6 x 32x32x16): %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t1, t1 / t0, ms[1], mhz[1]);
   printf("2 x f16  (3 x 32x32x16): %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t2, t2 / t0, ms[2], mhz[2]);
   printf("2 x f16  (as 16x16x32) : %7.1f TFLOP/s fp32-equivalent (%.2fx)  %6.1f ms at %4.0f MHz\n", t3, t3 / t0, ms[3], mhz[3]);
+  run<4>(out, clk, 200000, &mhz[4], &ms[4]);
+  printf("same count of 16x16x16 : %6.1f ms at %4.0f MHz for as many instructions as the line above (half the FLOPs each): %.2f of its time\n",
+         ms[4], mhz[4], ms[4] / ms[3]);
   return 0;
 }
