@@ -38,9 +38,16 @@
 #include "sr3d_split_f16.h"
 
 #include <limits.h>
+#include <utility>
 #include <stdlib.h>
 
 
+// timing-only ablation builds (results WRONG by construction), a bit mask: 1 no halo refill, 2 no weight DMA, 4 no barriers,
+// 8 no weight-fragment reads, 16 no halo-fragment reads, 32 one MFMA of the three, 64 no raw-row loads (the rest of the refill
+// stays), 128 no maxima / scale / split arithmetic, 256 no accumulator flip, 512 no halo write + chunk barrier (tools/abl_hconv.sh)
+#ifndef HCONV_NWB_F32
+#define HCONV_NWB_F32 2
+#endif
 #ifndef HCONV_ABL
 #define HCONV_ABL 0
 #endif
@@ -66,7 +73,12 @@ struct HGeo {
   // Weight buffers: the LDS-DMA of a phase is issued NWB - 1 phases before its fragments are read.  The split form has 48
   // MFMAs (768 cycles) per phase, enough to cover one DMA (issue -> landed 250-400 cycles from L2); the bf16 form has 16
   // (256 cycles) and was bound by exactly that latency with two buffers (606 TFLOP/s): it runs three phases ahead.
-  static constexpr int NWB = BF ? 4 : 2;
+  // (split form with THREE buffers, two phases ahead -- 80 KB per workgroup, the CU's 160 KB exactly -- was measured too:
+  // vector-memory operations complete in issue order, so waiting for the next phase's weights also waits for the raw-row
+  // loads of the next chunk issued in phase 0, and two phases of distance leave those in flight one phase longer.  No gain
+  // (up1 forward 42.1 vs 42.5 ms, profiles/r03f_layers_hconv_weight_buffers.log): the loads cost issue slots, not latency.
+  // -DHCONV_NWB_F32=3 builds it.)
+  static constexpr int NWB = BF ? 4 : HCONV_NWB_F32;
   // Tap pairs per phase (= per barrier, per weight DMA, per wait).  bf16: TWO -- with 16 MFMAs per phase the ~45 scalar and
   // ~40 vector bookkeeping instructions of a phase and its barrier were 3 + 2.4 per MFMA and the matrix pipe stood at 35 %
   // (profiles/r03d_pmc_instruction_mix_up1_bf16.json; weight DMA distance, halo double-buffering and wider halo loads had
@@ -85,16 +97,42 @@ static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU
 
 
 
-// PAIR (bf16 only, even X): the halo is fetched as 4-byte PAIRS of x-neighbours (32 instead of 56 loads per lane and chunk).
+template <class F, int... I>
+__device__ __forceinline__ void hconv_static_for(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+// s_waitcnt vmcnt(n) lgkmcnt(0) for the counts the kernel uses (n folds to a constant in the unrolled phase loop)
+__device__ __forceinline__ void hconv_wait_vm(const int n) {
+#define SR3D_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
+  switch (n) {
+    SR3D_W(0) SR3D_W(1) SR3D_W(2) SR3D_W(3) SR3D_W(4) SR3D_W(6)
+    SR3D_W(16) SR3D_W(17) SR3D_W(18) SR3D_W(20)
+    SR3D_W(32) SR3D_W(33) SR3D_W(34) SR3D_W(35) SR3D_W(36) SR3D_W(38)
+    SR3D_W(56) SR3D_W(57) SR3D_W(58) SR3D_W(59) SR3D_W(60) SR3D_W(62)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+  }
+#undef SR3D_W
+}
+
+// PAIR = wide halo loads.
+// bf16 (even X): the halo is fetched as 4-byte PAIRS of x-neighbours (32 instead of 56 loads per lane and chunk).
 // The bf16 form has a third of the MFMAs per chunk, and with one 2-byte load per voxel and channel the vector-memory
 // instruction rate (~22 cycles per wave instruction, 8 waves per CU) became its limit: a timing-only build WITHOUT the halo
 // refill ran 37 % shorter (profiles/r03d_ablation_hconv_kernel_bf16.log).
+// fp32 (X % 4 == 0): 16-byte QUADS of x-neighbours, 16 instead of 56 loads per lane and chunk: a lane takes quad q of a
+// halo row (x = x0 - 4 + 4 q .. + 3; the outer quads contribute one column each) for its 8 channels and holds 4 voxels x 8
+// channels = four 16-byte pieces per part, no cross-lane exchange.  The timing-only build of the split form without the
+// raw-row loads (everything else kept) ran 20 % shorter, and more prefetch distance did not help: the loads cost
+// instruction slots of the texture path, not latency (profiles/r03e_ablation_hconv_kernel_fp32.log).
 template <int RT, bool BF, bool PAIR>
 __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
-  static_assert(BF || !PAIR, "pair loads are the bf16 path");
   using G = HGeo<RT, BF>;
-  constexpr int NR = PAIR ? 4 : HNR;           // staging rounds
-  constexpr int HPX = 18;                      // PAIR: pairs per halo row, covering hx = -1 .. 34
+  constexpr bool BPAIR = BF && PAIR, QUAD = !BF && PAIR;
+  constexpr int NR = BPAIR ? 4 : QUAD ? 2 : HNR;   // staging rounds
+  constexpr int RV = QUAD ? 4 : 1;             // voxels per lane and round and channel in `raw`
+  constexpr int HPX = 18;                      // bf16 pairs per halo row, covering hx = -1 .. 34
+  constexpr int HQX = 10;                      // fp32 quads per halo row, covering hx = -3 .. 36
   constexpr int NP = G::NP;
   constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -132,11 +170,20 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   const int sh = wave & 1;
   unsigned soff[NR];    // byte offset inside a channel volume, 0xffffffff = zero padding
   int swr[NR];          // byte offset of the 16-byte piece inside a halo plane (PAIR: of the pair's first voxel; < 0: none)
-  int swr2[NR];         // PAIR: of the pair's second voxel (< 0: none)
+  int swr2[NR];         // bf16 PAIR: of the pair's second voxel (< 0: none); fp32 QUAD: 4-bit mask of the quad's voxels inside the halo
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int e = (r * 2 + (wave >> 1)) * 64 + lane;
-    if constexpr (PAIR) {   // pair pp of row (hz, hy): x = x0 - 2 + 2 pp, + 1  <->  halo columns hx = 2 pp - 1, 2 pp
+    if constexpr (QUAD) {   // quad q of row (hz, hy): x = x0 - 4 + 4 q .. + 3  <->  halo columns hx = 4 q - 3 .. 4 q
+      const int row = e / HQX, q = e - row * HQX;
+      const int hz = row / HHY, hy = row - hz * HHY;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 4 + 4 * q;
+      const bool inrow = e < HHZ * HHY * HQX;
+      const bool ok = inrow && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;   // X % 4 == 0: all four or none
+      soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
+      swr[r] = ((hz * HHY + hy) * HHX + 4 * q - 3) * 16;   // (of the quad's first voxel; may lie outside the row)
+      swr2[r] = !inrow ? 0 : q == 0 ? 8 : q == HQX - 1 ? 1 : 15;
+    } else if constexpr (BPAIR) {   // pair pp of row (hz, hy): x = x0 - 2 + 2 pp, + 1  <->  halo columns hx = 2 pp - 1, 2 pp
       const int hz = e / (HHY * HPX), r2 = e - hz * (HHY * HPX);
       const int hy = r2 / HPX, pp = r2 - hy * HPX;
       const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 2 + 2 * pp;
@@ -177,8 +224,32 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
     return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
   };
-  float raw[NR][8];
+  float raw[NR][8 * RV];   // [round][channel][voxel of the quad]
+  // QUAD: channel c of this wave's 8, both rounds (two 16-byte loads per lane)
+  auto load_raw_q = [&](const int chunk, const int c) {
+    if constexpr (QUAD) {
+      const int gc = chunk * HKC + sh * 8 + c;   // wave-uniform
+      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        if constexpr ((HCONV_ABL & 64) != 0) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) asm volatile("" : "=v"(raw[r][c * 4 + v]));
+          continue;
+        }
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[r], 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; v++) raw[r][c * 4 + v] = __builtin_bit_cast(float, (unsigned)t[v]);
+      }
+    }
+  };
   auto load_raw = [&](const int chunk) {
+    if constexpr (QUAD) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) load_raw_q(chunk, c);
+      return;
+    }
     const int gc0 = chunk * HKC + sh * 8;      // wave-uniform
     const int first = gc0 < p.K ? gc0 : p.K - 1, last = gc0 + 7 < p.K ? gc0 + 7 : p.K - 1;
     unsigned long long cbase[8];
@@ -195,6 +266,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cbase[c], 0, gc0 + c < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
       for (int r = 0; r < NR; r++) {
+        if constexpr ((HCONV_ABL & 64) != 0) {   // ablation: an opaque definition, no load
+#pragma unroll
+          for (int v = 0; v < RV; v++) asm volatile("" : "=v"(raw[r][c * RV + v]));
+          continue;
+        }
         if constexpr (BF && !PAIR)   // the 16 bits of the bf16 element, zero-extended
           raw[r][c] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, soff[r], 0, 0));
         else                         // fp32 element, or two bf16 x-neighbours
@@ -210,13 +286,19 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   float rmax0 = 0.f, rmax1 = 0.f, rmax2 = 0.f, rmax3 = 0.f;
   auto publish_max = [&](const int parity, const int ck) {
     if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
+    if constexpr ((HCONV_ABL & 128) != 0) {   // ablation: the loads are waited for and consumed, no arithmetic
+#pragma unroll
+      for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int c = 0; c < 8 * RV; c++) asm volatile("" ::"v"(raw[r][c]));
+      return;
+    }
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < NR; r++)
-#pragma unroll
-      for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    for (int r = 0; r < NR; r++)   // (QUAD: the outer quads bring up to three columns from beyond the halo: elements of the
+#pragma unroll                     //  same tensor, so the tile scale is only more cautious and the exported maxima stay exact)
+      for (int c = 0; c < 8 * RV; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+    m = split_wave_max(m);
     if (lane == 0) xmax[parity * 4 + wave] = m;
     if (export_max) {
       const int gc0 = ck * HKC + sh * 8;
@@ -234,9 +316,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int c = 0; c < 8; c++) {
           float mc = 0.f;
 #pragma unroll
-          for (int r = 0; r < NR; r++) mc = fmaxf(mc, fabsf(raw[r][c]));
+          for (int r = 0; r < NR; r++)
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+            for (int v = 0; v < RV; v++) mc = fmaxf(mc, fabsf(raw[r][c * RV + v]));
+          mc = split_wave_max(mc);
           credit(slice_of(gc0 + c < p.K ? gc0 + c : p.K - 1), mc);
         }
       }
@@ -249,11 +332,41 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
   };
-  h8 chi[NR], clo[NR];   // halo pieces of the next chunk, split (PAIR: the two voxels of the pair)
+  h8 chi[NR * RV], clo[NR * RV];   // halo pieces of the next chunk, split (bf16 PAIR: the two voxels of the pair; QUAD: [round][voxel])
+  // QUAD: one voxel of one round: 8 channels scaled and split = 24 vector instructions, placed next to 24 MFMAs
+  auto convert_sub = [&](const int r, const int v, const float in_mult) {
+    if constexpr (QUAD) {
+      if constexpr ((HCONV_ABL & 128) != 0) {
+        asm volatile("" : "=v"(chi[r * 4 + v]), "=v"(clo[r * 4 + v]));
+        return;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float sc = raw[r][c * 4 + v] * in_mult;
+        const _Float16 a = (_Float16)sc;
+        chi[r * 4 + v][c] = a;
+        clo[r * 4 + v][c] = (_Float16)(sc - (float)a);
+      }
+    }
+  };
   auto convert = [&](const float in_mult) {
+    if constexpr ((HCONV_ABL & 128) != 0) {
+#pragma unroll
+      for (int r = 0; r < NR; r++) asm volatile("" : "=v"(chi[r]), "=v"(clo[r]));
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      if constexpr (PAIR) {   // dword c = (voxel 0, voxel 1) of channel c  ->  two 16-byte pieces of 8 channels
+      if constexpr (QUAD) {   // (prologue only: the chunk loop spreads convert_sub over four phases)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          convert_sub(r, v, in_mult);
+          asm volatile("" : "+v"(chi[r * 4 + v]), "+v"(clo[r * 4 + v]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
+      if constexpr (BPAIR) {   // dword c = (voxel 0, voxel 1) of channel c  ->  two 16-byte pieces of 8 channels
         u32x4 p0, p1;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -292,7 +405,16 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
     unsigned char* Hw = Hs + buf * G::HB;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      if constexpr (PAIR) {
+      if constexpr (QUAD) {
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          if ((swr2[r] >> v) & 1) {
+            *reinterpret_cast<h8*>(Hw + (0 * 2 + sh) * HPLANE + swr[r] + v * 16) = chi[r * 4 + v];
+            *reinterpret_cast<h8*>(Hw + (1 * 2 + sh) * HPLANE + swr[r] + v * 16) = clo[r * 4 + v];
+          }
+        continue;
+      }
+      if constexpr (BPAIR) {
         if (swr[r] >= 0) *reinterpret_cast<h8*>(Hw + sh * HPLANE + swr[r]) = chi[r];
         if (swr2[r] >= 0) *reinterpret_cast<h8*>(Hw + sh * HPLANE + swr2[r]) = clo[r];
         continue;
@@ -353,22 +475,35 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int s_next = s_run;
+  float in_mult_next = 1.f;
 
   // halo byte offset of tap t = (kz, ky, kx); the dummy tap 27 reads where tap 26 does (its weights are zero)
   auto tap_off = [](const int t) { const int u = t > 26 ? 26 : t; return (((u / 9) * HHY + (u / 3) % 3) * HHX + u % 3) * 16; };
   int phase = 0;
+  int wb = 0;            // weight buffer of the current phase = phase % NWB (running: NWB = 3 is not a power of two)
+  auto wb_plus = [](const int w, const int a) { const int t = w + a; return t >= NWB ? t - NWB : t; };
   for (int chunk = 0; chunk < p.nchunks; chunk++) {
-#pragma unroll   // (rolled, the next chunk's raw rows and their split form are both live in every phase: spills)
-    for (int kzy = 0; kzy < NPH; kzy++, phase++) {
-      const unsigned char* W0 = Ws + (phase & (NWB - 1)) * G::WPH + abase;
+    // (the phases as instantiations of one generic lambda: kzy is a compile-time constant in each -- a `#pragma unroll` loop
+    // is only a request, and rolled the next chunk's raw rows and their split form would both be live in every phase)
+    auto phase_body = [&](auto kz) {
+      constexpr int kzy = decltype(kz)::value;
+      const unsigned char* W0 = Ws + wb * G::WPH + abase;
       // Phase 1: this wave's share of the next chunk has landed (issued in phase 0): publish its largest magnitude.
       // Phase 2 (behind the barrier of phase 1): all four maxima -> scale of the next chunk; split its rows.  Both before
       // this phase's DMA is issued: hipcc does not see the hand-written waits and guards the first use of `raw` with its
       // own vmcnt(0).
       // (bf16: nothing to publish or scale; the rows are packed in the LAST phase, so that the raw registers and their
       // packed form are never live together and the loads have the whole chunk to land)
-      if (HCONV_ABL != 1 && !BF && kzy == 1) publish_max((chunk + 1) & 1, chunk + 1);
-      if (HCONV_ABL != 1 && kzy == (BF ? AHEAD + 1 : 2)) {
+      // QUAD: the raw rows of the next chunk come one channel (two 16-byte loads) per phase in phases 0..7 -- issued in one
+      // burst, the 8 waves' loads stood in the texture path in front of the following phases' weight DMAs --, the maxima are
+      // published at the end of phase 8, and phases 9..12 scale and split two voxels each NEXT to their MFMAs (one vector
+      // instruction per MFMA, in its shadow) instead of in a block of ~200 in front of them.
+      constexpr int QLOAD = 8, QPUB = 8, QCONV = 9;
+      if (!(HCONV_ABL & 1) && QUAD && kzy == QCONV) {
+        s_next = next_scale((chunk + 1) & 1, s_run);
+        in_mult_next = ldexpf(1.f, s_next);
+      }
+      if (!(HCONV_ABL & 1) && !QUAD && kzy == AHEAD + 1) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         convert(ldexpf(1.f, s_next));
         // bf16: straight into the OTHER halo buffer (nobody has read it since the previous chunk; the per-phase barriers
@@ -376,9 +511,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         if constexpr (BF && G::HBUF == 2) write_halo((chunk + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (HCONV_ABL != 2 && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + ((phase + AHEAD) & (NWB - 1)) * G::WPH);
+      if (!(HCONV_ABL & 2) && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + wb_plus(wb, AHEAD) * G::WPH);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
-      if (HCONV_ABL != 1 && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+      if (!(HCONV_ABL & 1) && !QUAD && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+      if (!(HCONV_ABL & 1) && QUAD && kzy < QLOAD) load_raw_q(chunk + 1, kzy);
 #pragma unroll
       for (int sub = 0; sub < PP; sub++) {
       const int pair = kzy * PP + sub;
@@ -389,7 +525,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
 #pragma unroll
       for (int part = 0; part < NP; part++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
+        for (int j = 0; j < 4; j++)
+          if (!(HCONV_ABL & 16) || pair == 0) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
       // row tiles two at a time (12 LDS reads in flight at most: 16 overflow the lgkmcnt counter model)
 #pragma unroll
       for (int ih = 0; ih < NRT; ih += 2) {
@@ -397,8 +534,23 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         for (int part = 0; part < NP; part++)
 #pragma unroll
           for (int i = 0; i < 2; i++)
-            if (HCONV_ABL != 4 || (pair == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
+            if (!(HCONV_ABL & 8) || (pair == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (QUAD && !(HCONV_ABL & 1)) {
+          if (kzy >= QCONV && kzy < QCONV + 4) {   // 8 (round, voxel) units over 4 phases: one per half (RT = 2), two (RT = 1)
+            constexpr int UPH = 2 / (NRT / 2);     // units per half
+#pragma unroll
+            for (int u = 0; u < UPH; u++) {
+              const int unit = (kzy - QCONV) * 2 + (ih / 2) * UPH + u;
+              convert_sub(unit >> 2, unit & 3, in_mult_next);
+            }
+#pragma unroll
+            for (int g = 0; g < 24; g++) {         // MFMA, vector op, MFMA, vector op, ...
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, UPH, 0);
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -407,50 +559,61 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
               acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
                                                                        acc[ih + i][j], 0, 0, 0);
             } else {
-              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NP - 1][j], acc[ih + i][j], 0, 0, 0);
-              acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NP - 1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+              if (!(HCONV_ABL & 32)) {
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NP - 1][j], acc[ih + i][j], 0, 0, 0);
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NP - 1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+              }
               acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
             }
           }
+        if constexpr (QUAD && !(HCONV_ABL & 1)) {   // the split pieces exist HERE (hipcc would sink the arithmetic to the stores behind the chunk)
+          if (kzy >= QCONV && kzy < QCONV + 4) {
+            constexpr int UPH = 2 / (NRT / 2);
+#pragma unroll
+            for (int u = 0; u < UPH; u++) {
+              const int unit = (kzy - QCONV) * 2 + (ih / 2) * UPH + u;
+              asm volatile("" : "+v"(chi[unit]), "+v"(clo[unit]));
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       }   // sub
       // The NEXT phase's weights have landed (vector-memory operations complete in issue order).  Younger than their DMA
-      // and allowed to stay in flight: the DMAs of the AHEAD - 1 phases after it, and -- in the first AHEAD phases of a
-      // chunk -- the 8 * HNR raw-row loads of the next chunk, which are issued right after the DMA of phase 0.
-      if constexpr (AHEAD == 1) {
-        if (kzy == 0)
-          asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else {
-        // bf16 form: 3 phases ahead, two tap pairs per phase -> every wave issues ND DMAs per phase (64-row blocks: 8 pieces
-        // over 4 waves; 32-row blocks: 4), so 2 * ND are younger than the one waited for
-        static_assert(AHEAD == 3 && G::PP == 2 && (G::PIECES == 4 || G::PIECES == 2), "wait counts below");
-        constexpr int ND = G::PP * G::PIECES / 4;
-        if (phase + AHEAD >= nphases) {            // the last phases: nothing new was issued
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else if (kzy < AHEAD) {                  // + the 8 * NR raw-row loads of the next chunk
-          if constexpr (ND == 2 && PAIR) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
-          if constexpr (ND == 2 && !PAIR) asm volatile("s_waitcnt vmcnt(60) lgkmcnt(0)" ::: "memory");
-          if constexpr (ND == 1 && PAIR) asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");
-          if constexpr (ND == 1 && !PAIR) asm volatile("s_waitcnt vmcnt(58) lgkmcnt(0)" ::: "memory");
-        } else {
-          if constexpr (ND == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-          if constexpr (ND == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      // and allowed to stay in flight: the DMAs of the AHEAD - 1 phases after it (ND instructions per wave and phase: 64-row
+      // blocks of the split form 8 pieces over 4 waves, ...), and -- in the first AHEAD phases of a chunk -- the 8 * NR
+      // raw-row loads of the next chunk, which are issued right after the DMA of phase 0.  In phase AHEAD they have landed
+      // (waited for together with the DMA issued behind them): this wave's share of the next chunk publishes its largest
+      // magnitude before the barrier, and phase AHEAD + 1 picks the four maxima up, scales and splits.
+      {
+        constexpr int ND = (G::PP * G::PIECES + 3) / 4, NRAW = 8 * NR;
+        static_assert(G::PP * G::PIECES % 4 == 0 || G::PP * G::PIECES < 4, "every wave issues the same number of DMAs");
+        if (!(HCONV_ABL & 1) && !BF && !QUAD && kzy == AHEAD) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND * (AHEAD - 1)) : "memory");   // (the compiler's own wait would be vmcnt(0))
+          publish_max((chunk + 1) & 1, chunk + 1);
         }
+        if (!(HCONV_ABL & 1) && QUAD && kzy == QPUB) publish_max((chunk + 1) & 1, chunk + 1);   // (no load was issued in this phase)
+        if (phase + AHEAD >= nphases)              // the last phases: nothing new was issued
+          hconv_wait_vm(0);
+        else if constexpr (QUAD)                   // behind the DMA: this phase's two loads
+          hconv_wait_vm(ND * (AHEAD - 1) + (kzy < QLOAD ? NR : 0));
+        else
+          hconv_wait_vm(ND * (AHEAD - 1) + (kzy < AHEAD ? NRAW : 0));
       }
-      if (HCONV_ABL != 3) __builtin_amdgcn_s_barrier();
-    }
+      if (!(HCONV_ABL & 4)) __builtin_amdgcn_s_barrier();
+      wb = wb_plus(wb, 1);
+      phase++;
+    };
+    hconv_static_for(phase_body, std::make_integer_sequence<int, NPH>{});
     if constexpr (G::HBUF == 2) continue;   // (double-buffered halo: written during the chunk)
-    if (HCONV_ABL != 1 && chunk + 1 < p.nchunks) {
+    if (!(HCONV_ABL & 1) && chunk + 1 < p.nchunks) {
       // The f16 MFMA truncates inside its adder tree: every accumulation step leaves a tiny NEGATIVE error whatever the
       // sign of the sum (measured: mean error -5e-7 of the output rms at K = 1032, against 3e-10 for the fp32 MFMA; the
       // normwise error is the same).  A bias adds up coherently in sums over a million voxels (bias gradients were
       // 5e-5 off).  So the packed weights alternate sign from chunk to chunk and the accumulators are negated in
       // between: the result is unchanged and the truncation errors of successive chunks cancel.  (The same multiply
       // moves the accumulators to the next chunk's scale when that chunk is larger than everything before it.)
-      if constexpr (!BF) {   // (bf16: the weights keep their sign, nothing to rescale)
+      if constexpr (!BF && !(HCONV_ABL & 256)) {   // (bf16: the weights keep their sign, nothing to rescale)
         const float flip = -ldexpf(1.f, s_next - s_run);
 #pragma unroll
         for (int i = 0; i < NRT; i++)
@@ -458,9 +621,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
           for (int j = 0; j < 4; j++) acc[i][j] *= flip;
       }
       s_run = s_next;
-      write_halo(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(HCONV_ABL & 512)) {
+        write_halo(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
 
@@ -816,9 +981,11 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
   row_split(p.N, &n2, &n1);
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
-  if (!bf) return hconv_launch_t<false, false>(p, B, n2, n1, nsp, st);
-  // bf16: pair loads need even rows and 4-byte aligned tensors
-  bool pair = p.X % 2 == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
-  for (int i = 0; i < p.in.n; i++) pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 3) == 0;
+  // wide halo loads: fp32 quads need X % 4 == 0 and 16-byte aligned tensors (then every channel row is), bf16 pairs even
+  // rows and 4-byte aligned tensors
+  const int wide = bf ? 2 : 4;
+  bool pair = p.X % wide == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
+  for (int i = 0; i < p.in.n; i++) pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 3 : 15)) == 0;
+  if (!bf) return pair ? hconv_launch_t<false, true>(p, B, n2, n1, nsp, st) : hconv_launch_t<false, false>(p, B, n2, n1, nsp, st);
   return pair ? hconv_launch_t<true, true>(p, B, n2, n1, nsp, st) : hconv_launch_t<true, false>(p, B, n2, n1, nsp, st);
 }

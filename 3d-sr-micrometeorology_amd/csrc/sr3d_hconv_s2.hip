@@ -175,8 +175,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     for (int r = 0; r < HNR; r++)
 #pragma unroll
       for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = split_wave_max(m);
     if (lane == 0) xmax[parity * 4 + wave] = m;
   };
   auto next_scale = [&](const int parity, const int s_run) {

@@ -52,6 +52,22 @@ __device__ __forceinline__ float split_act(float v, int act) {
   return v;
 }
 
+// Largest value of a non-negative float over the 64 lanes of the wave, returned wave-uniform.  Four DPP steps inside the
+// rows of 16 lanes (quad swaps, half-row mirror, row mirror) and four lane reads: vector-ALU only.  (__shfl_xor is a
+// ds_bpermute per step: six dependent trips through the LDS pipe, ~700 cycles in front of a barrier.)
+__device__ __forceinline__ float split_wave_max(float m) {
+#define SR3D_DPP_MAX(ctrl) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), ctrl, 0xf, 0xf, false)))
+  SR3D_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
+  SR3D_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
+  SR3D_DPP_MAX(0x141);   // row_half_mirror
+  SR3D_DPP_MAX(0x140);   // row_mirror
+#undef SR3D_DPP_MAX
+  const int mi = __builtin_bit_cast(int, m);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // max |x| of a tensor into *slot with atomicMax (bits of a non-negative float order like unsigned integers; the caller
 // zeroes the slot).  Defined in sr3d_hconv.hip.
 int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st);
