@@ -196,13 +196,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
         continue;
       }
       h8 hi, lo;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const float sc = raw[r][c] * in_mult;
-        const _Float16 a = (_Float16)sc;
-        hi[c] = a;
-        lo[c] = (_Float16)(sc - (float)a);
-      }
+      split_piece(&raw[r][0], 1, in_mult, hi, lo);
       *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;   // (rounds 0..4 stay below voxel 640: no slot there)
       *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
     }

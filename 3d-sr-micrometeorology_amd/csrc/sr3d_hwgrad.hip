@@ -183,15 +183,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       for (int j = 0; j < 10; j++) pv[j] = 0.f;
     }
   };
-  auto split8 = [&](const float* pv, const int off, const float mult, h8& hi, h8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const float s = pv[off + j] * mult;
-      const _Float16 a = (_Float16)s;
-      hi[j] = a;
-      lo[j] = (_Float16)(s - (float)a);
-    }
-  };
+  auto split2 = [&](const float a, const float b, const float mult, unsigned& hi, unsigned& lo) { split_pair(a, b, mult, hi, lo); };
   // X row (plane slot, y slot) / dY buffer addresses
   auto write_piece = [&](const int st, const int yslot_x, const int dbuf, const float dsign) {
     if (!stager) return;
@@ -219,20 +211,33 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       return;
     }
     if (is_x) {
-      h8 hi, lo;
-      split8(pv, 1, mx, hi, lo);
-      unsigned char* d = Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16;
-      *reinterpret_cast<h8*>(d) = hi;
-      *reinterpret_cast<h8*>(d + 32 * PITCH) = lo;
-    } else {
+      unsigned hi[4], lo[4];
 #pragma unroll
-      for (int cp = 0; cp < 3; cp++) {   // copy cp holds dY[x' - cp + 1]: element j of the piece = pv[1 + j - cp + 1]
-        h8 hi, lo;
-        split8(pv, 2 - cp, md * dsign, hi, lo);
-        unsigned char* d = Ds + dbuf * G::DROW + cp * G::DCOPY + it_n * PITCH + it_q * 16;
-        *reinterpret_cast<h8*>(d) = hi;
-        *reinterpret_cast<h8*>(d + 32 * RT * PITCH) = lo;
+      for (int k = 0; k < 4; k++) split2(pv[1 + 2 * k], pv[2 + 2 * k], mx, hi[k], lo[k]);
+      unsigned char* d = Xs + (it_dz * 4 + yslot_x) * XROW + it_c * PITCH + it_q * 16;
+      *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<u32x4*>(d + 32 * PITCH) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    } else {
+      // the 10 elements -1 .. 8 are split ONCE, as the pairs (-1, 0), (1, 2), ..., (7, 8); copy cp holds dY[x' - cp + 1]:
+      //   cp = 0: elements 1 .. 8 = pairs 1 .. 4;  cp = 2: elements -1 .. 6 = pairs 0 .. 3;
+      //   cp = 1: elements 0 .. 7 = the high half of pair k with the low half of pair k + 1 (v_alignbit)
+      const float m = md * dsign;
+      unsigned ph[5], pl[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) split2(pv[2 * k], pv[2 * k + 1], m, ph[k], pl[k]);
+      unsigned char* d = Ds + dbuf * G::DROW + it_n * PITCH + it_q * 16;
+      *reinterpret_cast<u32x4*>(d) = u32x4{ph[1], ph[2], ph[3], ph[4]};
+      *reinterpret_cast<u32x4*>(d + 32 * RT * PITCH) = u32x4{pl[1], pl[2], pl[3], pl[4]};
+      u32x4 mh, ml;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        mh[k] = __builtin_amdgcn_alignbit(ph[k + 1], ph[k], 16);
+        ml[k] = __builtin_amdgcn_alignbit(pl[k + 1], pl[k], 16);
       }
+      *reinterpret_cast<u32x4*>(d + G::DCOPY) = mh;
+      *reinterpret_cast<u32x4*>(d + G::DCOPY + 32 * RT * PITCH) = ml;
+      *reinterpret_cast<u32x4*>(d + 2 * G::DCOPY) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+      *reinterpret_cast<u32x4*>(d + 2 * G::DCOPY + 32 * RT * PITCH) = u32x4{pl[0], pl[1], pl[2], pl[3]};
     }
   };
 

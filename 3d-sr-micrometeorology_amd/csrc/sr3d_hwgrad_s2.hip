@@ -176,13 +176,7 @@ __global__ __launch_bounds__(WNT) void hwgrad_s2_kernel(const Hw2Params p) {
   };
   // 8 values pv[off], pv[off + st], ... scaled and split
   auto split8 = [&](const int off, const int st, const float mult, h8& hi, h8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const float s = pv[off + st * j] * mult;
-      const _Float16 a = (_Float16)s;
-      hi[j] = a;
-      lo[j] = (_Float16)(s - (float)a);
-    }
+    split_piece(&pv[off], st, mult, hi, lo);
   };
   // X item -> row slot `xslot` of its plane, both parities; dY item -> buffer dbuf, both copies
   auto write_piece = [&](const int xslot, const int dbuf, const float dsign) {
