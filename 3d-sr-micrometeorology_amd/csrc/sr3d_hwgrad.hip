@@ -9,8 +9,8 @@
 // fragment is one aligned ds_read_b128.
 //
 // Workgroup = 12 waves: an (n-block of 32 * RT rows) x (c-block of 32 channels) x (x segment of 32 voxels) x (a range
-// of (b, z, y) rows, split-K).  Waves 0..8 own the taps (kz, ky) = (w / 3, w % 3) x kx 0, 1; waves 9..11 kx = 2 of three
-// (kz, ky) groups each (balanced over the four SIMDs, see the kernel).
+// of (b, z, y) rows, split-K).  Wave w owns one 16-row tile of the n block and one kz plane: 9 taps x 2 channel tiles,
+// 54 MFMAs per step on every wave (see "wave roles" in the kernel).
 // It marches along y: per step ONE new X row of each of the 3 z planes (4 y slots per plane in LDS) and one dY row
 // (3 shifted copies, double-buffered) are staged, by waves 0-5 (X) and 6-9 (dY), one 8-voxel piece per thread,
 // loaded a step ahead into registers, then scaled, split and written; one barrier per step.
@@ -241,29 +241,30 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
     }
   };
 
-  // The whole marching loop exists once per wave role (compile-time FEW): with one loop and a run-time role the
-  // register allocator shuffled the accumulators between the two MFMA sections and spilled 436 bytes.
-  auto run = [&](auto few_tag) {
-  constexpr bool FEW = decltype(few_tag)::value;
+  // ---- wave roles.  Wave w = (16-row tile i of the n block, kz plane[, 16-channel tile]): all 9 (ky, kx) taps of ITS plane
+  // for ITS rows.  Per step it reads the three shifted dY copies of its row tile once (6 fragments) and per ky one X row
+  // of its plane (2 channel tiles x [hi | lo] = 4 fragments; 32-row blocks: one channel tile, 2), and multiplies
+  // 9 x 2 x 3 = 54 MFMAs: 18 fragment reads per 54 MFMAs, the same 54 on every wave and SIMD.  (The first version gave
+  // each wave a (kz, ky) group with kx = 0, 1 and three waves the kx = 2 taps: 24 - 36 reads per 48 - 72 MFMAs, every wave
+  // re-reading all four row tiles -- a third more LDS traffic -- and 144 / 168 / 168 / 168 MFMAs on the four SIMDs.)
   // v_mfma_f32_16x16x32_f16: one MFMA reduces over the WHOLE 32-voxel row segment; the tiles are 16 rows x 16 channels
-  // (4 accumulator registers).  Same products and fragment reads as with 32x32x16, but the 16x16x32 shape is 14 % more
-  // power-efficient on this part (tools/mfma_rate.hip), and this kernel runs at the power limit.
-  constexpr int NT = 2 * RT;                  // 16-row tiles of the n block; 2 16-channel tiles of the c block
-  constexpr int NK = FEW ? 3 : 2;             // accumulator slots (see below)
-  f32x4 acc[NK][NT][2];
+  // (4 accumulator registers); the 16x16x32 shape is 14 % more power-efficient than 32x32x16 on this part
+  // (tools/mfma_rate.hip), and this kernel runs at the power limit.
+  constexpr int NT = 2 * RT;                  // 16-row tiles of the n block
+  constexpr int JW = 12 / (3 * NT);           // waves sharing a (row tile, plane): 1 (64-row blocks) or 2 (32-row blocks)
+  constexpr int NJ = 2 / JW;                  // 16-channel tiles per wave
+  const int wi = wave % NT, wkz = (wave / NT) % 3, wj = wave / (3 * NT);
+  f32x4 acc[3][3][NJ];                        // [ky][kx][channel tile]
 #pragma unroll
-  for (int k = 0; k < NK; k++)
+  for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int i = 0; i < NT; i++)
+    for (int k = 0; k < 3; k++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) acc[k][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int jj = 0; jj < NJ; jj++) acc[a][k][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
   float acc_sign = 1.f;
-  // Accumulator slots.  The 27 taps are 9 (kz, ky) groups x 3 kx; 9 waves with a group each would sit 3-2-2-2 on the four
-  // SIMDs (75 % of the matrix pipes busy at best).  So: waves 0..8 own group w with kx = 0, 1, waves 9..11 own kx = 2 of
-  // the groups 3(w-9) .. +2: 12 / 14 / 14 / 14 units per SIMD.
-  const int g0 = FEW ? 3 * (wave - 9) : wave;
   const int fr = (lane & 15) * PITCH + (lane >> 4) * 16;   // fragment: row / channel lane & 15, voxels 8 (lane >> 4) .. +8
-  auto xrow = [&](const int g, const int t) { return Xs + ((g / 3) * 4 + ((t + (g % 3) - 1) & 3)) * XROW + fr; };
+  const int fa = wi * 16 * PITCH + fr;                      // this wave's row tile inside a dY copy
+  const int fb = wkz * 4 * XROW + wj * NJ * 16 * PITCH + fr;   // its plane and first channel tile inside the X rows
 
   // ---- rows of this split
   const long long rows_total = (long long)p.B * p.Z * p.Y;
@@ -297,44 +298,42 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
         const float sgn = ((rr >> 5) & 1) ? -1.f : 1.f;
         if (sgn != acc_sign) {   // (wave-uniform) sign alternation, see the header
 #pragma unroll
-          for (int k = 0; k < NK; k++)
+          for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int i = 0; i < NT; i++)
+            for (int k = 0; k < 3; k++)
 #pragma unroll
-              for (int j = 0; j < 2; j++) acc[k][i][j] = -acc[k][i][j];
+              for (int jj = 0; jj < NJ; jj++) acc[a][k][jj] = -acc[a][k][jj];
           acc_sign = sgn;
         }
-        const unsigned char* db = Ds + (t & 1) * G::DROW + fr;
-        // slot k: (X row, dY copy) = (group g0, copy k) for waves 0..8, (group g0 + k, copy 2) for waves 9..11
+        const unsigned char* da = Ds + (t & 1) * G::DROW + fa;
+        h8 ah[3], al[3];   // the three shifted copies of this wave's dY rows: copy k holds dY[x' - k + 1]
 #pragma unroll
-        for (int k = 0; k < NK; k++) {
-          const unsigned char* xb = xrow(FEW ? g0 + k : g0, t);
-          h8 bq[2][2];   // [channel tile][hi | lo]
+        for (int k = 0; k < 3; k++) {
+          ah[k] = *reinterpret_cast<const h8*>(da + k * G::DCOPY);
+          if constexpr (!BF) al[k] = *reinterpret_cast<const h8*>(da + k * G::DCOPY + 32 * RT * PITCH);
+        }
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            bq[j][0] = *reinterpret_cast<const h8*>(xb + j * 16 * PITCH);
-            if constexpr (!BF) bq[j][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + j * 16 * PITCH);
+        for (int a = 0; a < 3; a++) {   // ky: X row t + ky - 1 of the plane
+          const unsigned char* xb = Xs + fb + ((t + a - 1) & 3) * XROW;
+          h8 bq[NJ][2];   // [channel tile][hi | lo]
+#pragma unroll
+          for (int jj = 0; jj < NJ; jj++) {
+            bq[jj][0] = *reinterpret_cast<const h8*>(xb + jj * 16 * PITCH);
+            if constexpr (!BF) bq[jj][1] = *reinterpret_cast<const h8*>(xb + 32 * PITCH + jj * 16 * PITCH);
           }
-          const unsigned char* da = db + (FEW ? 2 : k) * G::DCOPY;
 #pragma unroll
-          for (int i = 0; i < NT; i++) {
-            const h8 ah = *reinterpret_cast<const h8*>(da + i * 16 * PITCH);
-            if constexpr (BF) {
+          for (int k = 0; k < 3; k++)
 #pragma unroll
-              for (int j = 0; j < 2; j++)
-                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ah), __builtin_bit_cast(bf8, bq[j][0]),
-                                                                       acc[k][i][j], 0, 0, 0);
-            } else {
-              const h8 al = *reinterpret_cast<const h8*>(da + 32 * RT * PITCH + i * 16 * PITCH);
-#pragma unroll
-              for (int j = 0; j < 2; j++) {
-                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][1], acc[k][i][j], 0, 0, 0);
-                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[j][0], acc[k][i][j], 0, 0, 0);
-                acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[j][0], acc[k][i][j], 0, 0, 0);
+            for (int jj = 0; jj < NJ; jj++) {
+              if constexpr (BF) {
+                acc[a][k][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ah[k]), __builtin_bit_cast(bf8, bq[jj][0]),
+                                                                        acc[a][k][jj], 0, 0, 0);
+              } else {
+                acc[a][k][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bq[jj][1], acc[a][k][jj], 0, 0, 0);
+                acc[a][k][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[k], bq[jj][0], acc[a][k][jj], 0, 0, 0);
+                acc[a][k][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bq[jj][0], acc[a][k][jj], 0, 0, 0);
               }
             }
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // (not __syncthreads(): that would drain vmcnt and expose the latency of the loads issued above in every step;
@@ -348,25 +347,20 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
 
   // ---- partial block -> slab[split, segment][tap][n][c]; 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-  for (int k = 0; k < NK; k++) {
-    const int tap = FEW ? (g0 + k) * 3 + 2 : g0 * 3 + k;
-    float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
+  for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int i = 0; i < NT; i++)
+    for (int k = 0; k < 3; k++) {
+      const int tap = (wkz * 3 + a) * 3 + k;
+      float* out = p.slab + ((long long)(split * p.nseg + seg) * 27 + tap) * p.Npad * p.Cpad;   // x segments are splits too
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int jj = 0; jj < NJ; jj++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int n = nb * (32 * RT) + i * 16 + 4 * (lane >> 4) + r;
-          const int c = cb * 32 + j * 16 + (lane & 15);
-          out[(long long)n * p.Cpad + c] = acc[k][i][j][r] * acc_sign;
+          const int n = nb * (32 * RT) + wi * 16 + 4 * (lane >> 4) + r;
+          const int c = cb * 32 + (wj * NJ + jj) * 16 + (lane & 15);
+          out[(long long)n * p.Cpad + c] = acc[a][k][jj][r] * acc_sign;
         }
-  }
-  };
-  if (wave >= 9)
-    run(std::true_type{});
-  else
-    run(std::false_type{});
+    }
 }
 
 // amax[i] = max over the 64 hashed slots of slice i, for the slices whose maxima another kernel exported
@@ -514,17 +508,13 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   p.xcd_order = getenv("SR3D_HWGRAD_XCD") ? atoi(getenv("SR3D_HWGRAD_XCD")) : (bf ? 1 : 0);
   const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
-  // prefetch distance (see the kernel): SR3D_HWGRAD_PF = 0 | 1 | 2 overrides the default (A/B timing)
-  int pf = bf ? 1 : 0;   // (measured: 0 / 1 / 2 within 1 % of each other in both forms -- the kernel is not latency-bound)
-  if (const char* e = getenv("SR3D_HWGRAD_PF")) pf = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+  // (a register ring that issued the loads one or two steps further ahead -- template parameter PF -- measured within 1 % in
+  // both forms, profiles/r03a_ab_hwgrad_prefetch_distance_xcd_order.log: the kernel is not latency-bound; only PF = 0 is built)
   (void)vox;
   {
     SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * c_used * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
     int rc;
-    if (bf)
-      rc = pf == 0 ? hw_launch<true, 0>(g.rt, nwg, p, st) : (pf == 1 ? hw_launch<true, 1>(g.rt, nwg, p, st) : hw_launch<true, 2>(g.rt, nwg, p, st));
-    else
-      rc = pf == 0 ? hw_launch<false, 0>(g.rt, nwg, p, st) : (pf == 1 ? hw_launch<false, 1>(g.rt, nwg, p, st) : hw_launch<false, 2>(g.rt, nwg, p, st));
+    rc = bf ? hw_launch<true, 0>(g.rt, nwg, p, st) : hw_launch<false, 0>(g.rt, nwg, p, st);
     if (rc) return rc;
   }
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
