@@ -24,6 +24,7 @@ namespace {
 
 
 constexpr int HKC = 16;
+constexpr int S2FLIP_SH = 2;                   // the packed weights and the accumulators change sign every 4 virtual chunks
 constexpr int HHY = 6, HHX = 34;               // LDS pitches of sr3d_hconv.hip; used region 3 x 5 x 33
 constexpr int UZ = 3, UY = 5, UX = 33;
 constexpr int HNR = 5;                         // staging rounds: voxel indices < 3 * 6 * 34 = 612 <= 10 * 64
@@ -46,8 +47,14 @@ static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU
 __host__ __device__ inline int tap_h(int mode, int par, int i) { return mode == 1 ? (par ? i : 1) : (par ? 1 - i : 0); }
 __host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
 
-template <int RT, int MODE, bool BF>
+// QD (input gradient, fp32, IX % 4 == 0, 16-byte aligned tensors): the dY halo rows are contiguous in x and are fetched as
+// 16-byte QUADS: wave w stages channels 4w .. 4w + 3 of the chunk, a lane takes quad q of halo row (hz, hy) -- 15 rows x 9
+// quads = 135 tasks in 3 rounds -- 12 loads per lane and chunk instead of 40.  The kernel was bound by the NUMBER of
+// vector-memory instructions (~22 cycles of the texture path per wave instruction: 320 per chunk pair of a CU against
+// 2600 cycles of MFMAs); a lane then holds 4 voxels x 4 channels and writes 8-byte half pieces.
+template <int RT, int MODE, bool BF, bool QD = false>
 __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params p) {
+  static_assert(!QD || (MODE == 2 && !BF), "quad loads: the fp32 input gradient");
   using G = SGeo<RT, BF>;
   constexpr int NP = G::NP;
   constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
@@ -115,6 +122,23 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     }
     smask[r] = m;
   }
+  constexpr int QNR = 3, QPR = 9;     // rounds; quads per halo row (hx = 4 q .. 4 q + 3, the last one holds column 32 only)
+  unsigned qoff[QNR];                 // byte offset of the quad inside a channel volume (0xffffffff: zero padding)
+  int qwr[QNR], qmask[QNR];           // LDS byte offset of the quad's first voxel; its voxels inside the halo
+  if constexpr (QD) {
+#pragma unroll
+    for (int r = 0; r < QNR; r++) {
+      const int t = r * 64 + lane;
+      const int row = t / QPR, q = t - row * QPR;
+      const int hz = row / UY, hy = row - hz * UY;
+      const int gz = z0 + hz, gy = y0 + hy, gx = x0 + 4 * q;
+      const bool task = t < UZ * UY * QPR;
+      const bool ok = task && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;   // IX % 4 == 0: all four or none
+      qoff[r] = ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * 4u : 0xffffffffu;
+      qwr[r] = ((hz * HHY + hy) * HHX + 4 * q) * 16;
+      qmask[r] = !task ? 0 : (q == QPR - 1 ? 1 : 15);
+    }
+  }
 
   // per-slice base pointers in scalar registers, mask arithmetic (see sr3d_hconv.hip)
 #define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
@@ -140,7 +164,24 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   // (class, chunk-in-class) of a virtual chunk are kept as running counters: no divisions in the loop
 
   float raw[HNR][8];
+  float rawq[QNR][16];   // QD: [round][channel 0..3][voxel of the quad]
   auto load_raw = [&](const int vc, const int kc_, const int cc_) {   // kc_: K-side class (mode 1), cc_: 16-channel chunk
+    if constexpr (QD) {
+      const bool live = vc < NV;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int gc = cc_ * HKC + wave * 4 + c;   // wave-uniform
+        const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < QNR; r++) {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, qoff[r], 0, 0);
+#pragma unroll
+          for (int v = 0; v < 4; v++) rawq[r][c * 4 + v] = __builtin_bit_cast(float, (unsigned)t[v]);
+        }
+      }
+      return;
+    }
     const int kc = MODE == 1 ? kc_ : 0;                            // (mode 2: dy is not subsampled)
     const int cc = cc_;
     const bool live = vc < NV;
@@ -171,10 +212,17 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   auto publish_max = [&](const int parity) {
     if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
+    if constexpr (QD) {   // (the last quad of a row brings three columns from beyond the halo: the tile scale is only more cautious)
 #pragma unroll
-    for (int r = 0; r < HNR; r++)
+      for (int r = 0; r < QNR; r++)
 #pragma unroll
-      for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+        for (int c = 0; c < 16; c += 2) m = fmaxf(fmaxf(m, fabsf(rawq[r][c])), fabsf(rawq[r][c + 1]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < HNR; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+    }
     m = split_wave_max(m);
     if (lane == 0) xmax[parity * 4 + wave] = m;
   };
@@ -185,6 +233,23 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     return s_c < s_run ? s_c : s_run;
   };
   auto split_and_write = [&](const float in_mult) {
+    if constexpr (QD) {   // channels 4 w .. 4 w + 3 = bytes 8 (w & 1) .. + 7 of the 16-byte piece of channel half w >> 1
+      unsigned char* H0 = Hs + (wave >> 1) * HPLANE + (wave & 1) * 8;
+#pragma unroll
+      for (int r = 0; r < QNR; r++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          unsigned h0, l0, h1, l1;
+          split_pair(rawq[r][0 * 4 + v], rawq[r][1 * 4 + v], in_mult, h0, l0);
+          split_pair(rawq[r][2 * 4 + v], rawq[r][3 * 4 + v], in_mult, h1, l1);
+          if ((qmask[r] >> v) & 1) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(H0 + qwr[r] + v * 16) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(H0 + 2 * HPLANE + qwr[r] + v * 16) = u32x2{l0, l1};
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < HNR; r++) {
       if constexpr (BF) {   // the 8 channels of a voxel, packed: the MFMA operand as it is
@@ -293,26 +358,39 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
             }
         }
       }
-      // next phase's weights landed (older than the 8 * HNR raw-row loads issued in phase 0)
-      if (ph == 0)
-        asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
-      else
+      // The chunk's LAST phase also publishes the maxima of the next chunk's rows (landed: they are waited for here), so
+      // that its barrier serves the exchange too -- a chunk has 1 .. 4 phases of 12 .. 24 MFMAs per wave, and a separate
+      // publish-and-barrier round after them was a third of the synchronisation of the kernel.
+      if (last && vc + 1 < NV) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_max((vc + 1) & 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (ph == 0) {   // next phase's weights landed (older than the 8 * HNR (QD: 4 * 3) raw-row loads issued in phase 0)
+        if constexpr (QD)
+          asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       woff += wsize;
     }
     if (vc + 1 < NV) {
-      publish_max((vc + 1) & 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
       const int s_next = next_scale((vc + 1) & 1, s_run);
-      const float flip = -ldexpf(1.f, s_next - s_run);   // sign alternation + rescale, see sr3d_hconv.hip
+      // sign alternation + rescale, see sr3d_hconv.hip: the sign turns every 2^S2FLIP_SH chunks (a chunk here is short: 12 .. 96
+      // MFMAs per wave against 32 packed multiplies for the 64 accumulator registers), and the multiply is skipped when
+      // there is neither a turn nor a new scale
+      const bool turn = (((vc + 1) >> S2FLIP_SH) ^ (vc >> S2FLIP_SH)) & 1;
+      if (!BF && (turn || s_next != s_run)) {
+        const float flip = ldexpf(turn ? -1.f : 1.f, s_next - s_run);
 #pragma unroll
-      for (int i = 0; i < RT; i++)
+        for (int i = 0; i < RT; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+          for (int j = 0; j < 2; j++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+            for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+      }
       s_run = s_next;
       split_and_write(ldexpf(1.f, s_run));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -323,7 +401,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   }
 
   // ------------------------------------------------------------------ epilogue
-  const float out_mult = ldexpf((NV & 1) ? 1.f : -1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
+  const float out_mult = ldexpf((!BF && (((NV - 1) >> S2FLIP_SH) & 1)) ? -1.f : 1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
   const int ox = x0 + (lane & 31);
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
@@ -457,7 +535,7 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
           val = w[(long long)k * kstride + tap];
         }
       }
-      const float s = val * ((vc & 1) ? -w_mult : w_mult);
+      const float s = val * ((((vc >> S2FLIP_SH) & 1) && !p.bf) ? -w_mult : w_mult);
       const _Float16 a = (_Float16)s;
       hi[j] = a;
       lo[j] = (_Float16)(s - (float)a);
@@ -486,13 +564,13 @@ inline void row_split(int rows, int* n2, int* n1) {
   *n1 = (rem > 0 && rem <= 32) ? 1 : 0;
 }
 
-template <int MODE, bool BF>
+template <int MODE, bool BF, bool QD = false>
 void launch_rt(int rt, dim3 grid, hipStream_t st, const SrHconvS2Params& p) {
   constexpr size_t lds2 = SGeo<2, BF>::LDS, lds1 = SGeo<1, BF>::LDS;
   if (rt == 2)
-    hipLaunchKernelGGL((hconv_s2_kernel<2, MODE, BF>), grid, dim3(HNT), lds2, st, p);
+    hipLaunchKernelGGL((hconv_s2_kernel<2, MODE, BF, QD>), grid, dim3(HNT), lds2, st, p);
   else
-    hipLaunchKernelGGL((hconv_s2_kernel<1, MODE, BF>), grid, dim3(HNT), lds1, st, p);
+    hipLaunchKernelGGL((hconv_s2_kernel<1, MODE, BF, QD>), grid, dim3(HNT), lds1, st, p);
 }
 
 template <bool BF>
@@ -502,6 +580,10 @@ int set_attrs() {
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  if constexpr (!BF) {
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  }
   return SR3D_OK;
 }
 
@@ -606,8 +688,14 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
     const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
     if (mode == 1)
       bf ? launch_rt<1, true>(rt, grid, st, q) : launch_rt<1, false>(rt, grid, st, q);
-    else
-      bf ? launch_rt<2, true>(rt, grid, st, q) : launch_rt<2, false>(rt, grid, st, q);
+    else if (bf)
+      launch_rt<2, true>(rt, grid, st, q);
+    else {
+      // quad loads of the dY rows: IX % 4 == 0 and 16-byte aligned tensors (then every channel row is)
+      bool quad = p.IX % 4 == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
+      for (int i = 0; i < p.in.n; i++) quad = quad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 15) == 0;
+      quad ? launch_rt<2, false, true>(rt, grid, st, q) : launch_rt<2, false, false>(rt, grid, st, q);
+    }
   }
   sr3d_prof_end(tok, st);
   SR3D_HIP(hipGetLastError());
