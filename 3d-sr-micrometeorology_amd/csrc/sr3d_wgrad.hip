@@ -563,12 +563,23 @@ inline size_t wino_wgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
 inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
   if (d->dtype == SR3D_DTYPE_BF16) return d->stride == 1 && d->X % 8 == 0;   // bf16 form of the kernel, any size
   const int mode = sr3d_hconv_mode();
-  if (mode == 0 || d->stride != 1 || d->Cin < 32 || n_total < 16 || d->X % 8 != 0) return false;
+  if (mode == 0 || d->stride != 1 || d->Cin < 32 || d->X % 8 != 0) return false;
   if (mode == 2) return true;
+  // (the 4-row `last` layer, 69 -> 4 at full resolution: 3.7 ms here -- 4 of the 32 rows of a block used -- against 4.4 ms on the
+  //  small-N VALU kernel, profiles/r03p_layers_last_wgrad.log)
+  if (n_total < 16) return (long long)d->B * d->Z * d->Y * d->X >= 1000000;
   // measured against the Winograd-domain kernel: faster from U-Net level 2 up (128 k voxels), and on level 3 for the
   // 2056-row layers; slower on the 256-row layers of levels 3-4
   const long long vox = (long long)d->B * d->Z * d->Y * d->X;
   return vox >= 100000 || (n_total >= 1024 && vox >= 16000);
+}
+// ... few input channels (conv0: 5) on its (channel, kx)-column form (sr3d_hwgrad_fc.hip), fp32 storage, grids that fill the chip
+inline bool use_hwgrad_fc(const sr3d_conv_desc_t* d, int n_total) {
+  if (d->dtype != SR3D_DTYPE_F32 || d->stride != 1 || d->Cin > 5 || n_total < 16 || d->X % 8 != 0) return false;
+  const int mode = sr3d_hconv_mode();
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  return (long long)d->B * d->Z * d->Y * d->X >= 100000;
 }
 // ... and the stride-2 layers on its de-interleaving form (sr3d_hwgrad_s2.hip): bf16 always; fp32 where the grid fills the
 // chip (U-Net levels 0-2; SR3D_SPLIT_F16 as above)
@@ -593,6 +604,7 @@ inline bool wino_wgrad_slices_ok(const sr3d_slice_t* dy_srcs, int n_dy) {
 }
 
 inline bool use_smalln(const sr3d_conv_desc_t* d, int n_total, int n_dy) {
+  if (use_hwgrad(d, n_total)) return false;
   return n_total <= 4 && n_dy == 1 && d->stride == 1 && d->Cin <= 65535 && d->dtype != SR3D_DTYPE_BF16;
 }
 
@@ -734,6 +746,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
   if (use_wino_wgrad(d, n_total)) bytes = std::max(bytes, wino_wgrad_total_ws(d, n_total));
   if (use_hwgrad(d, n_total)) bytes = std::max(bytes, hwgrad_total_ws(d, n_total));
   if (use_hwgrad_s2(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_s2_ws_bytes(d, n_total));
+  if (use_hwgrad_fc(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_fc_ws_bytes(d, n_total));
   return bytes;
 }
 
@@ -785,6 +798,19 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
       SR3D_CHECK(workspace_bytes >= sr3d_hwgrad_s2_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
                  "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
       return sr3d_hwgrad_s2(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream, (const unsigned*)x_absmax,
+                            (const unsigned*)dy_absmax);
+    }
+  }
+  if (use_hwgrad_fc(d, n_total)) {
+    ChanCat xc, dc;
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
+    if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
+    for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+    if (sr3d_hwgrad_fc_ok(d, xc, dc)) {
+      SR3D_CHECK(workspace_bytes >= sr3d_hwgrad_fc_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
+                 "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+      return sr3d_hwgrad_fc(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream, (const unsigned*)x_absmax,
                             (const unsigned*)dy_absmax);
     }
   }

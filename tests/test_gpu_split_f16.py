@@ -121,9 +121,38 @@ def test_split_f16_stride2_layers_vs_fp64(eng, forced, cs, cout, grid, kind, sca
     ([32, 1, 33], 130, (5, 9, 72), "plain"),
     ([40], 64, (7, 30, 48), "plain"),
     ([64, 2], 36, (3, 26, 40), "gated"),
+    ([64, 5], 4, (4, 12, 32), "plain"),        # the `last` layer's shape: 4 rows of a 32-row block
 ])
 def test_split_f16_weight_gradient_vs_fp64(eng, forced, cs, cout, grid, kind):
     xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, 1.0, seed=3 * sum(cs) + cout)
+    dev = lambda t: t.detach().float().to(DEV)   # noqa: E731
+    grads = []
+    for _ in range(2):
+        xd = [dev(x).requires_grad_(x.requires_grad) for x in xs]
+        wfd, wgd, bd = dev(wf).requires_grad_(True), dev(wg).requires_grad_(True), dev(bias).requires_grad_(True)
+        if kind == "gated":
+            y = eng.ops.gated_conv3d_act(xd, wfd, wgd, None, bd, act="relu", stride=1)
+        else:
+            y = eng.ops.conv3d_act(xd, wfd, bd, act="lrelu", stride=1)
+        y.backward(dev(gy))
+        grads.append((wfd.grad.clone(), wgd.grad.clone() if kind == "gated" else None))
+    assert relerr(grads[0][0], wf.grad) < TOL
+    if kind == "gated":
+        assert relerr(grads[0][1], wg.grad) < TOL
+        assert torch.equal(grads[0][1], grads[1][1])
+    assert torch.equal(grads[0][0], grads[1][0])          # fixed-order split-K sum: bit-reproducible
+
+
+# few input channels (csrc/sr3d_hwgrad_fc.hip: Cin <= 5, the MFMA columns are (channel, kx) pairs): conv0's shape (4 features +
+# the mask, gated: two dY slices), one channel, three row blocks with a partial last one, several x segments and splits
+@pytest.mark.parametrize("cs,cout,grid,kind", [
+    ([4, 1], 64, (5, 9, 72), "gated"),
+    ([5], 24, (4, 26, 32), "plain"),
+    ([3], 130, (4, 12, 40), "plain"),
+    ([1], 16, (3, 30, 48), "plain"),
+])
+def test_split_f16_few_channel_weight_gradient_vs_fp64(eng, forced, cs, cout, grid, kind):
+    xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, 1.0, seed=7 * sum(cs) + cout)
     dev = lambda t: t.detach().float().to(DEV)   # noqa: E731
     grads = []
     for _ in range(2):
