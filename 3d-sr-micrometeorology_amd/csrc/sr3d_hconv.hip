@@ -98,10 +98,14 @@ static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU
 
 
 
-template <class F, int... I>
-__device__ __forceinline__ void hconv_static_for(F& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
+template <class F, class T, int... I>
+__device__ __forceinline__ void hconv_static_for(F& f, T tag, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}, tag), ...);
 }
+// HALF-CHUNK TAIL (split form): when the last chunk holds 1 .. 8 channels (K = 129, 194, 258: a mask or an odd feature
+// channel behind a multiple of 16; K = 5 and 4: conv0 and the input gradient of `last`), its MFMAs take K = 4 taps x 8
+// channels instead of 2 taps x 16: 7 phases instead of 14, no zero channel half multiplied (K = 129: 5.6 % of the layer's MFMAs).
+__host__ __device__ inline bool hconv_tail(int K, bool bf) { return !bf && (K & 15) >= 1 && (K & 15) <= 8; }
 
 // s_waitcnt vmcnt(n) lgkmcnt(0) for the counts the kernel uses (n folds to a constant in the unrolled phase loop)
 __device__ __forceinline__ void hconv_wait_vm(const int n) {
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   // ---- prologue
   constexpr int NWB = G::NWB, AHEAD = NWB - 1;
   constexpr int PP = G::PP, NPH = G::NPH;
-  const int nphases = p.nchunks * NPH;
+  const bool tail = hconv_tail(p.K, BF);
+  const int nphases = p.nchunks * NPH - (tail ? NPH / 2 : 0);
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
     if (a < nphases) dma_w(a, Ws + a * G::WPH);
@@ -472,11 +477,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
   int phase = 0;
   int wb = 0;            // weight buffer of the current phase = phase % NWB (running: NWB = 3 is not a power of two)
   auto wb_plus = [](const int w, const int a) { const int t = w + a; return t >= NWB ? t - NWB : t; };
-  for (int chunk = 0; chunk < p.nchunks; chunk++) {
-    // (the phases as instantiations of one generic lambda: kzy is a compile-time constant in each -- a `#pragma unroll` loop
-    // is only a request, and rolled the next chunk's raw rows and their split form would both be live in every phase)
-    auto phase_body = [&](auto kz) {
+  int chunk = 0;
+  const int nfull = p.nchunks - (tail ? 1 : 0);   // full 16-channel chunks; the half-chunk tail follows the loop
+  // (the phases as instantiations of one generic lambda: kzy is a compile-time constant in each -- a `#pragma unroll` loop
+  // is only a request, and rolled the next chunk's raw rows and their split form would both be live in every phase)
+  auto phase_body = [&](auto kz, auto tl) {
       constexpr int kzy = decltype(kz)::value;
+      constexpr bool TAIL = decltype(tl)::value;   // the half-chunk tail: phase kzy holds taps 4 kzy .. + 3 of channels 0..7
       const unsigned char* W0 = Ws + wb * G::WPH + abase;
       // Phase 1: this wave's share of the next chunk has landed (issued in phase 0): publish its largest magnitude.
       // Phase 2 (behind the barrier of phase 1): all four maxima -> scale of the next chunk; split its rows.  Both before
@@ -489,11 +496,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       // published at the end of phase 8, and phases 9..12 scale and split two voxels each NEXT to their MFMAs (one vector
       // instruction per MFMA, in its shadow) instead of in a block of ~200 in front of them.
       constexpr int QLOAD = 8, QPUB = 8, QCONV = 9;
-      if (!(HCONV_ABL & 1) && QUAD && kzy == QCONV) {
+      if (!(HCONV_ABL & 1) && !TAIL && QUAD && kzy == QCONV) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         in_mult_next = ldexpf(1.f, s_next);
       }
-      if (!(HCONV_ABL & 1) && !QUAD && kzy == AHEAD + 1) {
+      if (!(HCONV_ABL & 1) && !TAIL && !QUAD && kzy == AHEAD + 1) {
         s_next = next_scale((chunk + 1) & 1, s_run);
         convert(ldexpf(1.f, s_next));
         // bf16: straight into the OTHER halo buffer (nobody has read it since the previous chunk; the per-phase barriers
@@ -503,14 +510,21 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       __builtin_amdgcn_sched_barrier(0);
       if (!(HCONV_ABL & 2) && phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + wb_plus(wb, AHEAD) * G::WPH);
       __builtin_amdgcn_sched_barrier(0);    // (the wait below counts on this order)
-      if (!(HCONV_ABL & 1) && !QUAD && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
-      if (!(HCONV_ABL & 1) && QUAD && kzy < QLOAD) load_raw_q(chunk + 1, kzy);
+      if (!(HCONV_ABL & 1) && !TAIL && !QUAD && kzy == 0) load_raw(chunk + 1);    // (past the end: empty descriptors, zeros)
+      if (!(HCONV_ABL & 1) && !TAIL && QUAD && kzy < QLOAD) load_raw_q(chunk + 1, kzy);
 #pragma unroll
       for (int sub = 0; sub < PP; sub++) {
       const int pair = kzy * PP + sub;
       const unsigned char* W = W0 + sub * G::WPHASE;
       // this lane's halo offset for the pair: first tap on lanes 0..31, second on 32..63
-      const unsigned char* Hk = Hs + (G::HBUF == 2 ? (chunk & 1) * G::HB : 0) + (tap_b ? tap_off(2 * pair + 1) : tap_off(2 * pair));
+      const unsigned char* Hk;
+      if constexpr (TAIL) {   // lane group g = lane >> 4 supplies tap 4 kzy + g, always of channel half 0 (bbase carries (g & 1) halves)
+        const int g = lane >> 4;
+        const int o = g == 0 ? tap_off(4 * kzy) : g == 1 ? tap_off(4 * kzy + 1) : g == 2 ? tap_off(4 * kzy + 2) : tap_off(4 * kzy + 3);
+        Hk = Hs + o - (g & 1) * HPLANE;
+      } else {
+        Hk = Hs + (G::HBUF == 2 ? (chunk & 1) * G::HB : 0) + (tap_b ? tap_off(2 * pair + 1) : tap_off(2 * pair));
+      }
       h8 fb[NP][4], fa[NP][2];   // [hi | lo][voxel tile]; [hi | lo][row tile of the current half]
 #pragma unroll
       for (int part = 0; part < NP; part++)
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
           for (int i = 0; i < 2; i++)
             if (!(HCONV_ABL & 8) || (pair == 0 && ih == 0)) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (QUAD && !(HCONV_ABL & 1)) {
+        if constexpr (QUAD && !TAIL && !(HCONV_ABL & 1)) {
           if (kzy >= QCONV && kzy < QCONV + 4) {   // 8 (round, voxel) units over 4 phases: one per half (RT = 2), two (RT = 1)
             constexpr int UPH = 2 / (NRT / 2);     // units per half
 #pragma unroll
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
               acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
             }
           }
-        if constexpr (QUAD && !(HCONV_ABL & 1)) {   // the split pieces exist HERE (hipcc would sink the arithmetic to the stores behind the chunk)
+        if constexpr (QUAD && !TAIL && !(HCONV_ABL & 1)) {   // the split pieces exist HERE (hipcc would sink the arithmetic to the stores behind the chunk)
           if (kzy >= QCONV && kzy < QCONV + 4) {
             constexpr int UPH = 2 / (NRT / 2);
 #pragma unroll
@@ -578,13 +592,15 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       {
         constexpr int ND = (G::PP * G::PIECES + 3) / 4, NRAW = 8 * NR;
         static_assert(G::PP * G::PIECES % 4 == 0 || G::PP * G::PIECES < 4, "every wave issues the same number of DMAs");
-        if (!(HCONV_ABL & 1) && !BF && !QUAD && kzy == AHEAD) {
+        if (!(HCONV_ABL & 1) && !TAIL && !BF && !QUAD && kzy == AHEAD) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND * (AHEAD - 1)) : "memory");   // (the compiler's own wait would be vmcnt(0))
           publish_max((chunk + 1) & 1, chunk + 1);
         }
-        if (!(HCONV_ABL & 1) && QUAD && kzy == QPUB) publish_max((chunk + 1) & 1, chunk + 1);   // (no load was issued in this phase)
+        if (!(HCONV_ABL & 1) && !TAIL && QUAD && kzy == QPUB) publish_max((chunk + 1) & 1, chunk + 1);   // (no load was issued in this phase)
         if (phase + AHEAD >= nphases)              // the last phases: nothing new was issued
           hconv_wait_vm(0);
+        else if constexpr (TAIL)                   // (the last chunk: no rows are fetched)
+          hconv_wait_vm(ND * (AHEAD - 1));
         else if constexpr (QUAD)                   // behind the DMA: this phase's two loads
           hconv_wait_vm(ND * (AHEAD - 1) + (kzy < QLOAD ? NR : 0));
         else
@@ -594,7 +610,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
       wb = wb_plus(wb, 1);
       phase++;
     };
-    hconv_static_for(phase_body, std::make_integer_sequence<int, NPH>{});
+  for (; chunk < nfull; chunk++) {
+    hconv_static_for(phase_body, std::false_type{}, std::make_integer_sequence<int, NPH>{});
     if constexpr (G::HBUF == 2) continue;   // (double-buffered halo: written during the chunk)
     if (!(HCONV_ABL & 1) && chunk + 1 < p.nchunks) {
       // The f16 MFMA truncates inside its adder tree: every accumulation step leaves a tiny NEGATIVE error whatever the
@@ -622,6 +639,9 @@ __global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
         __builtin_amdgcn_s_barrier();
       }
     }
+  }
+  if constexpr (!BF) {   // the half-chunk tail (the refill state of the loop above is dead here)
+    if (tail) hconv_static_for(phase_body, std::true_type{}, std::make_integer_sequence<int, NPH / 2>{});
   }
 
   if (export_max && lane == 0) {   // (bits of a non-negative float order like unsigned integers)
@@ -800,6 +820,8 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
     const int n = p.n_off + nb * (32 * p.RT) + rt * 16 + row;
+    const bool tailc = hconv_tail(p.K, p.bf != 0) && chunk + 1 == p.nchunks;   // half-chunk tail: 4 taps x 8 channels per MFMA
+    if (tailc && h == 1) continue;                                             // (its second channel half does not exist)
     const float* w = nullptr;   // -> w[.][k = 0][tap 0]; element (k, tap) at w[k * kstride + tapidx]
     long long kstride = 27;
     int tapidx = tap;
@@ -842,13 +864,15 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
       wb[j] = (__bf16)s;
     }
     // fragment of (pair = tap / 2, part, tile): lane = row + 16 * (2 * (tap & 1) + h)  [MFMA K group = tap of the pair, half]
-    const int l = row + 16 * (2 * (tap & 1) + h);
+    int l = row + 16 * (2 * (tap & 1) + h);
+    int phs = tap / 2;
+    if (tailc) l = row + 16 * (tap & 3), phs = tap / 4;   // lane group = tap of the quad; phases 0 .. 6 of the chunk
     if (p.bf) {
       const long long frag = (((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * (2 * p.RT) + rt;
       *reinterpret_cast<bf8*>(p.img + frag * 512 + l * 8) = wb;
       continue;
     }
-    const long long frag0 = ((((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * 2 + 0) * (2 * p.RT) + rt;
+    const long long frag0 = ((((long long)nb * p.nchunks + chunk) * 14 + phs) * 2 + 0) * (2 * p.RT) + rt;
     const long long frag1 = frag0 + 2 * p.RT;
     *reinterpret_cast<h8*>(p.img + frag0 * 512 + l * 8) = hi;
     *reinterpret_cast<h8*>(p.img + frag1 * 512 + l * 8) = lo;

@@ -452,7 +452,8 @@ inline bool use_wino(const sr3d_conv_desc_t* d) {
 inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
   if (is_bf(d)) return d->stride == 1;
   const int mode = sr3d_hconv_mode();
-  if (d->stride != 1 || K < 32 || rows < 16 || mode == 0) return false;
+  // (K <= 8 -- conv0, the input gradient of `last` -- is ONE half chunk of the kernel: 7 phases; 9 .. 31 channels stay with Winograd)
+  if (d->stride != 1 || (K < 32 && K > 8) || rows < 16 || mode == 0) return false;
   if (mode == 2) return true;
   const long long wgs = (long long)d->B * ceil_div(d->Z, 2) * ceil_div(d->Y, 4) * ceil_div(d->X, 32) * ceil_div(rows, 64);
   return wgs >= 448;

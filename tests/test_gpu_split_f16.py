@@ -59,6 +59,9 @@ CASES = [
     ([64], 64, (4, 8, 32), "plain", 1e-7),
     ([128], 32, (4, 8, 32), "gated", 1.0),
     ([36, 1], 40, (5, 6, 35), "gated", 1.0),
+    ([4, 1], 64, (6, 10, 40), "gated", 1.0),     # conv0: K = 5 is ONE half chunk (4 taps x 8 channels per MFMA, 7 phases)
+    ([64, 5], 4, (6, 10, 40), "plain", 1.0),     # `last`: the input gradient has K = 4
+    ([128, 1], 40, (4, 8, 32), "plain", 1.0),    # 8 full chunks + a half-chunk tail of one channel
 ]
 
 
