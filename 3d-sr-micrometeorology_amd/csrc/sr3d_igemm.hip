@@ -455,17 +455,23 @@ inline bool use_hconv(const sr3d_conv_desc_t* d, int K, int rows) {
   // (K <= 8 -- conv0, the input gradient of `last` -- is ONE half chunk of the kernel: 7 phases; 9 .. 31 channels stay with Winograd)
   if (d->stride != 1 || (K < 32 && K > 8) || rows < 16 || mode == 0) return false;
   if (mode == 2) return true;
+  // (re-measured at the end of round 3, after the kernel's refill was restructured: faster than the Winograd kernel from U-Net
+  //  level 3 up whatever the launch size -- up3.up input gradient, 400 workgroups: 2.61 -> 2.04 ms; up4.convs: 0.68 -> 0.56 ms --
+  //  and equal on level 4, profiles/r03w_layers_small_grids_default_vs_forced.log; the threshold was 448)
   const long long wgs = (long long)d->B * ceil_div(d->Z, 2) * ceil_div(d->Y, 4) * ceil_div(d->X, 32) * ceil_div(rows, 64);
-  return wgs >= 448;
+  return wgs >= 100;
 }
 // ... and the stride-2 layers on its parity-class form (sr3d_hconv_s2.hip); bwd: 8 class launches over the coarse grid
-inline bool use_hconv_s2(const sr3d_conv_desc_t* d, int K, int rows) {
+inline bool use_hconv_s2(const sr3d_conv_desc_t* d, int K, int rows, bool bwd = false) {
   if (is_bf(d)) return d->stride == 2;
   const int mode = sr3d_hconv_mode();
   if (d->stride != 2 || K < 32 || rows < 16 || mode == 0) return false;
   if (mode == 2) return true;
   const int oz = (d->Z - 1) / 2 + 1, oy = (d->Y - 1) / 2 + 1, ox = (d->X - 1) / 2 + 1;
-  return (long long)d->B * ceil_div(oz, 2) * ceil_div(oy, 4) * ceil_div(ox, 32) * ceil_div(rows, 64) >= 448;
+  // (re-measured at the end of round 3, profiles/r03w_layers_small_grids_default_vs_forced.log: the input gradient is faster than
+  //  the 8-class fp32 kernel down to level 3 -- down3.0 1.32 -> 0.57 ms, down4.0 0.59 -> 0.24 ms --, the forward loses on
+  //  level 3's 120 workgroups: 0.46 -> 0.59 ms)
+  return (long long)d->B * ceil_div(oz, 2) * ceil_div(oy, 4) * ceil_div(ox, 32) * ceil_div(rows, 64) >= (bwd ? 50 : 200);
 }
 inline int hconv_fwd_rows(const sr3d_conv_desc_t* d, int kind) {
   return kind == SR3D_PACK_FWD_GATED ? 64 * ((d->Cout + 31) / 32) : d->Cout;
@@ -927,7 +933,7 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   const size_t hc = use_hconv(d, n_dy * d->Cout, d->Cin)
                         ? ((sr3d_hconv_image_bytes(d->Cin, n_dy * d->Cout, is_bf(d)) + 255) & ~(size_t)255) + (size_t)n_dy * d->Cout * 108 * 4
                         : 0;
-  const size_t hs2 = use_hconv_s2(d, n_dy * d->Cout, d->Cin) ? sr3d_hconv_s2_image_bytes(d->Cin, n_dy * d->Cout, is_bf(d)) : 0;
+  const size_t hs2 = use_hconv_s2(d, n_dy * d->Cout, d->Cin, true) ? sr3d_hconv_s2_image_bytes(d->Cin, n_dy * d->Cout, is_bf(d)) : 0;
   size_t m = direct > wino ? direct : wino;
   m = m > hc ? m : hc;
   return m > hs2 ? m : hs2;
@@ -1037,7 +1043,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     full_taps(p, C::HY, C::HX, true);
     return launch<1, -1, 1, 2, 4>(p, d->B, rp, image, st);
   }
-  if (use_hconv_s2(d, K, rows)) {
+  if (use_hconv_s2(d, K, rows, true)) {
     SrHconvS2Params q{};
     q.in = p.in, q.out = p.out, q.K = K, q.N = rows, q.n_off = 0;
     q.IZ = OZ, q.IY = OY, q.IX = OX;

@@ -568,10 +568,11 @@ inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
   // (the 4-row `last` layer, 69 -> 4 at full resolution: 3.7 ms here -- 4 of the 32 rows of a block used -- against 4.4 ms on the
   //  small-N VALU kernel, profiles/r03p_layers_last_wgrad.log)
   if (n_total < 16) return (long long)d->B * d->Z * d->Y * d->X >= 1000000;
-  // measured against the Winograd-domain kernel: faster from U-Net level 2 up (128 k voxels), and on level 3 for the
-  // 2056-row layers; slower on the 256-row layers of levels 3-4
+  // measured against the Winograd-domain kernel (profiles/r03w_layers_small_grids_default_vs_forced.log, after the wave roles
+  // and the split arithmetic of round 3): faster from U-Net level 3 up (16 k voxels: down3.1 0.80 -> 0.49 ms, up4.convs
+  // 0.84 -> 0.55 / 0.48 -> 0.26 ms), equal on level 4
   const long long vox = (long long)d->B * d->Z * d->Y * d->X;
-  return vox >= 100000 || (n_total >= 1024 && vox >= 16000);
+  return vox >= 10000;
 }
 // ... few input channels (conv0: 5) on its (channel, kx)-column form (sr3d_hwgrad_fc.hip), fp32 storage, grids that fill the chip
 inline bool use_hwgrad_fc(const sr3d_conv_desc_t* d, int n_total) {
@@ -589,7 +590,7 @@ inline bool use_hwgrad_s2(const sr3d_conv_desc_t* d, int n_total) {
   const int mode = sr3d_hconv_mode();
   if (mode == 0 || n_total < 16) return false;
   if (mode == 2) return true;
-  return (long long)d->B * d->Z * d->Y * d->X >= 400000;
+  return (long long)d->B * d->Z * d->Y * d->X >= 100000;   // (down3.0, 128 k voxels: 1.03 -> 0.49 ms; level 3: equal)
 }
 inline size_t hwgrad_total_ws(const sr3d_conv_desc_t* d, int n_total) {
   const int cu = wino_wgrad_c_used(d);
