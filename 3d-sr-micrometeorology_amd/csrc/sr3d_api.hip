@@ -53,7 +53,7 @@ bool sr3d_prof_active() { return g_prof_on; }
 void sr3d_prof_begin(int id, double work, hipStream_t st, void** token) {
   *token = nullptr;
   if (!g_prof_on) return;
-  if (g_prof_dominant_only && id != SR3D_PROF_HCONV && id != SR3D_PROF_IGEMM_S1) return;
+  if (g_prof_dominant_only && id != SR3D_PROF_HCONV && id != SR3D_PROF_HCONV_SMALL && id != SR3D_PROF_IGEMM_S1) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_next >= (int)g_prof.size()) { g_prof_dropped++; return; }
   ProfRec* r = &g_prof[g_prof_next++];

@@ -965,7 +965,9 @@ int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipSt
   void* tok = nullptr;
   if (sr3d_prof_active()) {
     const double rows = p.epi == SR3D_EPI_GATED ? 2.0 * p.Cg : (double)p.N;
-    sr3d_prof_begin(SR3D_PROF_HCONV, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
+    // (launches that do not fill the chip's 512 workgroup slots -- the small grids of U-Net levels 3-4 -- are a family of their own)
+    const bool fills = nsp * (n2 + n1) * B >= 448;
+    sr3d_prof_begin(fills ? SR3D_PROF_HCONV : SR3D_PROF_HCONV_SMALL, 2.0 * 27 * p.K * rows * (double)p.Z * p.Y * p.X * B, st, &tok);
   }
   constexpr size_t lds2 = HGeo<2, BF>::LDS, lds1 = HGeo<1, BF>::LDS;
   constexpr size_t wphase2 = HGeo<2, BF>::WPHASE;

@@ -48,7 +48,7 @@ TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_hbm_traffi
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 BYTES_PER_VOXEL = 11_586       # compulsory fwd+bwd activation traffic per HR voxel, fp32
 FAMILIES = {"igemm_s1": 0, "igemm_s2": 1, "igemm_bwd_s2": 2, "wgrad": 3, "loss": 4, "act_bwd": 5, "bias_grad": 6,
-            "adam": 7, "data": 8, "pack_reduce": 9, "hconv": 11}
+            "adam": 7, "data": 8, "pack_reduce": 9, "hconv": 11, "hconv_small": 12}
 
 DEFAULT_CONFIG = {
     "data": {"stds": [8.40, 14.40, 21.60, 7.00]},
@@ -358,7 +358,9 @@ def main():
                            "v_mfma_f32_16x16x32_f16, fp32 operands split into two fp16 halves (3 products), fp32 accumulate")
             note = ("achieved = f16 MFMA FLOPs the kernel EXECUTES per second = 3 x algorithmic FLOPs of the 3x3x3 "
                     "convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d); channel padding to 16 not counted) / kernel "
-                    "time from HIP events; peak = dense f16 MFMA at 2.4 GHz.  The f16 MFMA is POWER-bound on this part: "
+                    "time from HIP events, over the kernel's launches of >= 448 workgroups (they fill the chip; the launches on "
+                    "the small grids of U-Net levels 3-4 are listed as conv_kernels.hconv_small); peak = dense f16 MFMA at 2.4 "
+                    "GHz.  The f16 MFMA is POWER-bound on this part: "
                     f"tools/mfma_rate.hip sustains {F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s with the kernel's MFMA shape, 16x16x32 "
                     "(register operands only, 100 ms, clock settling at 1.89 GHz; 1674 with 32x32x16) -- frac_of_sustained is "
                     "against that")
@@ -373,7 +375,7 @@ def main():
         bd, bs = m["breakdown"] or prof, (m["breakdown_steps"] if m["breakdown"] else args.steps)
         conv = {k: {"ms_per_step": bd[k]["ms"] / bs, "launches_per_step": bd[k]["launches"] / bs,
                     "algorithmic_tflops": (bd[k]["work"] / (bd[k]["ms"] * 1e-3) / 1e12 if bd[k]["ms"] > 0 else 0.0)}
-                for k in ("hconv", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")}
+                for k in ("hconv", "hconv_small", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")}
         hbm = {k: {"ms_per_step": bd[k]["ms"] / bs, "launches_per_step": bd[k]["launches"] / bs,
                    "gbytes_per_s": (bd[k]["work"] / (bd[k]["ms"] * 1e-3) / 1e9 if bd[k]["ms"] > 0 else 0.0),
                    "frac_of_hbm_peak": (bd[k]["work"] / (bd[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -467,7 +469,7 @@ def main():
                              "kernel_ms_per_step": bp["ms"] / n5, "launches_per_step": bp["launches"] / n5},
                 "conv_kernels": {k: {"ms_per_step": bb[k]["ms"] / bf16_same["breakdown_steps"],
                                      "algorithmic_tflops": (bb[k]["work"] / (bb[k]["ms"] * 1e-3) / 1e12 if bb[k]["ms"] > 0 else 0.0)}
-                                 for k in ("hconv", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")},
+                                 for k in ("hconv", "hconv_small", "igemm_s1", "igemm_s2", "igemm_bwd_s2", "wgrad")},
                 "hbm_bound_kernels": {k: {"ms_per_step": bb[k]["ms"] / bf16_same["breakdown_steps"],
                                           "gbytes_per_s": (bb[k]["work"] / (bb[k]["ms"] * 1e-3) / 1e9 if bb[k]["ms"] > 0 else 0.0)}
                                       for k in ("loss", "act_bwd", "bias_grad", "adam", "data", "pack_reduce")}}

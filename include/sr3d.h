@@ -269,11 +269,13 @@ enum {
   SR3D_PROF_DATA = 8,         /* upsample+concat, mask pyramid, near-wall mask               [byte] */
   SR3D_PROF_PACK = 9,         /* weight packing / transforms and split-K reductions          [byte] */
   SR3D_PROF_EVAL = 10,        /* fused evaluation metrics                                    [byte] */
-  SR3D_PROF_HCONV = 11,       /* stride-1 conv on the split-f16 kernel (SR3D_SPLIT_F16=1)     [FLOP] */
-  SR3D_PROF_FAMILIES = 12,
+  SR3D_PROF_HCONV = 11,       /* stride-1 conv on the split-f16 kernel (SR3D_SPLIT_F16=1): launches of at least 448
+                                 workgroups, which fill the chip's 512 slots                                  [FLOP] */
+  SR3D_PROF_HCONV_SMALL = 12, /* ... its launches below that (U-Net levels 3-4: small grids, one partial round) [FLOP] */
+  SR3D_PROF_FAMILIES = 13,
   SR3D_PROF_DROPPED = 99      /* launches: records lost because the event pool was exhausted */
 };
-/* on = 1: every family; on = 2: only the stride-1 convolution families (SR3D_PROF_HCONV, SR3D_PROF_IGEMM_S1): bench.py
+/* on = 1: every family; on = 2: only the stride-1 convolution families (SR3D_PROF_HCONV, SR3D_PROF_HCONV_SMALL, SR3D_PROF_IGEMM_S1): bench.py
  * brackets only the dominant kernel inside its timed region (48 instead of ~1100 event records per training step) and
  * collects the other families in a separate, untimed pass; on = 0: off. */
 int sr3d_profile_enable(int on);

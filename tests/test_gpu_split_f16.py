@@ -92,6 +92,7 @@ S2_CASES = [
     ([33], 40, (5, 7, 33), "plain", 1.0),
     ([48], 130, (6, 9, 70), "plain", 50.0),
     ([40, 1, 24], 32, (7, 8, 34), "gated", 1e-6),
+    ([40], 48, (6, 10, 72), "plain", 1.0),        # coarse rows of 36: quad dY loads with a partial last x tile
 ]
 
 
