@@ -504,8 +504,9 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   p.nnb = g.nnb, p.ncb = g.ncb, p.nseg = g.nseg, p.S = g.S, p.rows_per_split = g.rows_per_split;
   p.Npad = g.Npad, p.Cpad = g.Cpad;
   p.slab = ws + 64, p.amax = (const float*)amax;
-  // (measured on the level-0/1 layers: +-3 % per layer either way in the split form, 1-5 % faster in the bf16 form)
-  p.xcd_order = getenv("SR3D_HWGRAD_XCD") ? atoi(getenv("SR3D_HWGRAD_XCD")) : (bf ? 1 : 0);
+  // (measured on the level-0/1 layers: 1-5 % faster in the bf16 form; in the split form +-3 % per layer in the first half of
+  //  round 3, 1 % faster after the kernel's vector work was cut -- profiles/r03f_ab_hwgrad_xcd_order_fp32.log)
+  p.xcd_order = getenv("SR3D_HWGRAD_XCD") ? atoi(getenv("SR3D_HWGRAD_XCD")) : 1;
   const long long nwg = (long long)g.nnb * g.ncb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "split-f16 weight gradient: grid too large");
   // (a register ring that issued the loads one or two steps further ahead -- template parameter PF -- measured within 1 % in
