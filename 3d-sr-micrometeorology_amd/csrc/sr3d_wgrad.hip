@@ -629,12 +629,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_partial_kernel(const T* __restrict__ dy, float* __restrict__ part,
                                                           int B, int C, long long vox, int nsplit) {
   const int c = blockIdx.y, sp = blockIdx.x;
-  const long long per = (vox + nsplit - 1) / nsplit;
+  const long long per = (((vox + nsplit - 1) / nsplit) + 3) & ~3ll;   // a multiple of 4: every split starts on a 16-byte piece
   const long long v0 = sp * per, v1 = (v0 + per < vox ? v0 + per : vox);
   float s = 0.f;
+  // four elements per load and four running sums (one 4-byte load per thread and a single dependent chain read at
+  // 3.3 TB/s); the order of the additions is fixed by the launch geometry: deterministic
+  const bool vec = vox % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
   for (int b = 0; b < B; b++) {
     const T* src = dy + ((long long)b * C + c) * vox;
-    for (long long v = v0 + threadIdx.x; v < v1; v += 256) s += ActIo<T>::ld(src + v);
+    if (vec) {
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+      for (long long v = v0 + 4 * threadIdx.x; v < v1; v += 4 * 256) a4 += ActIo<T>::ld4(src + v);
+      s += (a4.x + a4.y) + (a4.z + a4.w);
+    } else {
+      for (long long v = v0 + threadIdx.x; v < v1; v += 256) s += ActIo<T>::ld(src + v);
+    }
   }
   __shared__ float red[256];
   red[threadIdx.x] = s;
