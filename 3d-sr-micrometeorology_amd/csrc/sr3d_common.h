@@ -131,7 +131,9 @@ struct SrHconvS2Params {
   long long cls_off[8];    // mode 2: byte offset of the class image, bytes of one of its row blocks
   long long cls_blk[8];
   int cZ[8], cY[8], cX[8];
+  unsigned* amax_out;  // mode 1, optional [SR3D_MAX_SRC][64]: max |x| per K-side slice (as SrHconvParams.amax_out; fp32 only)
 };
+int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st);   // max |x| into *slot (sr3d_hconv.hip)
 size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf = false);
 int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
                        const int* rbeg, const int* cbeg, void* image, bool bf, hipStream_t st);

@@ -209,7 +209,11 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       }
     }
   };
-  auto publish_max = [&](const int parity) {
+  // per-slice maxima of |x| over this workgroup's halo tiles (forward, first row block): exported at the end for the
+  // split-f16 weight gradient of the same layer, as sr3d_hconv.hip does (the 8 parity classes together see every element)
+  const bool export_max = MODE == 1 && !BF && !QD && p.amax_out != nullptr && nblk == 0;
+  float rmax0 = 0.f, rmax1 = 0.f, rmax2 = 0.f, rmax3 = 0.f;
+  auto publish_max = [&](const int parity, const int cc_) {
     if constexpr (BF) return;   // no scaling: bf16 has fp32's exponent range
     float m = 0.f;
     if constexpr (QD) {   // (the last quad of a row brings three columns from beyond the halo: the tile scale is only more cautious)
@@ -225,6 +229,31 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     }
     m = split_wave_max(m);
     if (lane == 0) xmax[parity * 4 + wave] = m;
+    if constexpr (MODE == 1 && !BF && !QD) {
+      if (export_max) {
+        const int gc0 = cc_ * HKC + sh * 8;
+        auto slice_of = [&](const int gc) { return (gc >= cb1) + (gc >= cb2) + (gc >= cb3); };
+        const int sa = slice_of(gc0 < p.K ? gc0 : p.K - 1), sb = slice_of(gc0 + 7 < p.K ? gc0 + 7 : p.K - 1);
+        auto credit = [&](const int sl, const float mv) {
+          rmax0 = sl == 0 ? fmaxf(rmax0, mv) : rmax0;
+          rmax1 = sl == 1 ? fmaxf(rmax1, mv) : rmax1;
+          rmax2 = sl == 2 ? fmaxf(rmax2, mv) : rmax2;
+          rmax3 = sl == 3 ? fmaxf(rmax3, mv) : rmax3;
+        };
+        if (sa == sb) {
+          credit(sa, m);
+        } else {   // the 8 channels straddle a slice boundary: one maximum per channel
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            float mc = 0.f;
+#pragma unroll
+            for (int r = 0; r < HNR; r++) mc = fmaxf(mc, fabsf(raw[r][c]));
+            mc = split_wave_max(mc);
+            credit(slice_of(gc0 + c < p.K ? gc0 + c : p.K - 1), mc);
+          }
+        }
+      }
+    }
   };
   auto next_scale = [&](const int parity, const int s_run) {
     if constexpr (BF) return 0;
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
   int woff = 0, gph = 0;
   dma_w(0, nxp * NP * RT, Ws);
   load_raw(0, 0, 0);
-  publish_max(0);
+  publish_max(0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int s_run = next_scale(0, kSplitScaleNone);
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       // publish-and-barrier round after them was a third of the synchronisation of the kernel.
       if (last && vc + 1 < NV) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish_max((vc + 1) & 1);
+        publish_max((vc + 1) & 1, cc_n);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else if (ph == 0) {   // next phase's weights landed (older than the 8 * HNR (QD: 4 * 3) raw-row loads issued in phase 0)
         if constexpr (QD)
@@ -400,6 +429,13 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
     if (MODE == 1) cls = kcls_n;
   }
 
+  if (export_max && lane == 0) {   // (bits of a non-negative float order like unsigned integers)
+    unsigned* slot = p.amax_out + ((v / p.nblk) & 63);
+    if (rmax0 > 0.f) atomicMax(slot, __float_as_uint(rmax0));
+    if (rmax1 > 0.f) atomicMax(slot + 64, __float_as_uint(rmax1));
+    if (rmax2 > 0.f) atomicMax(slot + 128, __float_as_uint(rmax2));
+    if (rmax3 > 0.f) atomicMax(slot + 192, __float_as_uint(rmax3));
+  }
   // ------------------------------------------------------------------ epilogue
   const float out_mult = ldexpf((!BF && (((NV - 1) >> S2FLIP_SH) & 1)) ? -1.f : 1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
   const int ox = x0 + (lane & 31);

@@ -709,7 +709,7 @@ RowPlan fwd_plan(const sr3d_conv_desc_t* d, int rows, bool gated) {
 }
 
 int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, IgemmParams& p, int dst_scale,
-                   const float* image, hipStream_t st) {
+                   const float* image, hipStream_t st, void* x_absmax = nullptr) {
   const long long vox = (long long)d->Z * d->Y * d->X;
   if (int rc = sr3d_make_cat(x_srcs, n_src, vox, d->Cin, &p.in, "x_srcs")) return rc;
   for (int i = 0; i < p.in.n; i++) SR3D_CHECK(p.in.ptr[i] != nullptr, SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
@@ -726,9 +726,13 @@ int forward_common(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_
     q.N = p.N, q.n_off = 0, q.epi = p.epi, q.act = p.act, q.bias = p.bias, q.bias2 = p.bias2;
     q.out = p.out, q.y = p.y, q.save_f = p.save_f, q.save_s = p.save_s, q.Cg = p.Cg;
     q.TZ_ = p.TZ_, q.TY_ = p.TY_, q.TX_ = p.TX_;
+    q.amax_out = is_bf(d) ? nullptr : (unsigned*)x_absmax;
     return sr3d_hconv_s2_launch(1, q, image, d->B, is_bf(d), st);
   }
   SR3D_CHECK(!is_bf(d), SR3D_E_ARG, "bf16 activations: stride-2 convolution with the unshuffle epilogue is not implemented");
+  if (x_absmax != nullptr && d->stride == 2)   // (sr3d_conv3d_fwd_exports_absmax promised the maxima, this path has no by-product: sweep)
+    for (int i = 0; i < p.in.n; i++)
+      if (int rc = sr3d_absmax_launch(p.in.ptr[i], (long long)d->B * p.in.bstride[i], (unsigned*)x_absmax + 64 * i, st)) return rc;
   p.nchunks = ceil_div(p.K, kKC);
   const RowPlan rp = fwd_plan(d, p.N, p.epi == EPI_GATED);
   if (d->stride == 1) {
@@ -794,7 +798,7 @@ int sr3d_conv3d_fwd_exports_absmax(const sr3d_conv_desc_t* d, int gated) {
   if (check_desc(d) != SR3D_OK || is_bf(d)) return 0;
   const int kind = gated ? SR3D_PACK_FWD_GATED : SR3D_PACK_FWD;
   if (use_smalln_fwd(d, kind)) return 0;
-  return use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)) ? 1 : 0;
+  return (use_hconv(d, d->Cin, hconv_fwd_rows(d, kind)) || use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind))) ? 1 : 0;
 }
 
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
@@ -871,7 +875,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     sr3d_slice_t ys{y, d->Cout};
     if (int rc = sr3d_make_cat(&ys, 1, (long long)OZ * OY * OX, d->Cout, &p.out, "y")) return rc;
   }
-  return forward_common(d, x_srcs, n_src, p, unshuffle ? 2 : 1, (const float*)w_packed, (hipStream_t)stream);
+  return forward_common(d, x_srcs, n_src, p, unshuffle ? 2 : 1, (const float*)w_packed, (hipStream_t)stream, x_absmax);
 }
 
 int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
@@ -913,7 +917,7 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
   p.y = (float*)y, p.save_f = (float*)save_f, p.save_s = (float*)save_s;
   p.N = fwd_rows(d, SR3D_PACK_FWD_GATED);  // GEMM rows: feature/gate interleaved in blocks of 32
   p.Cg = d->Cout;
-  return forward_common(d, x_srcs, n_src, p, 1, (const float*)w_packed, (hipStream_t)stream);
+  return forward_common(d, x_srcs, n_src, p, 1, (const float*)w_packed, (hipStream_t)stream, x_absmax);
 }
 
 // rows of the backward GEMM = input channels that need a gradient (slices with a null ptr are skipped)

@@ -260,6 +260,29 @@ def test_unshuffle_layer_accepts_both_row_orders_and_exported_maxima_match_a_swe
     assert relerr(dw_fused, dw_sweep) < 2e-6
 
 
+def test_stride2_forward_exports_exact_slice_maxima(eng, forced):
+    """the stride-2 forward kernel (csrc/sr3d_hconv_s2.hip) exports max|x| per input slice like the stride-1 kernel: exact per
+    slice although the mask shares an 8-channel staging group with padding, ragged tiles, batch 2"""
+    import ctypes as C
+    from sr3d_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    x = ((torch.rand(2, 40, 6, 9, 48, generator=g) - 0.5) * 3.0).to(DEV)
+    m = (torch.rand(2, 1, 6, 9, 48, generator=g) > 0.3).float().to(DEV)
+    wf = (torch.randn(32, 41, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    wg = (torch.randn(32, 41, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    bg = (torch.randn(32, generator=g) * 0.1).to(DEV)
+    desc = L.conv_desc(2, 41, 32, 6, 9, 48, 2)
+    assert L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 1) == 1
+    wp = eng.ops.pack_weights(desc, L.PACK_FWD_GATED, wf, wg)
+    y, ff, ss = (torch.empty(2, 32, 3, 5, 24, device=DEV) for _ in range(3))
+    xa = torch.zeros(256, dtype=torch.int32, device=DEV)
+    L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices([x, m]), 2, L.dev_ptr(wp), None, L.dev_ptr(bg), L.dev_ptr(y),
+                                        L.dev_ptr(ff), L.dev_ptr(ss), L.ACT_RELU, C.c_void_p(xa.data_ptr()), L.stream_ptr()), "fwd")
+    got = xa.view(torch.float32).view(4, 64).amax(dim=1).cpu()
+    assert float(got[0]) == float(x.abs().max()) and float(got[1]) == 1.0
+    assert float(got[2]) == 0.0 and float(got[3]) == 0.0
+
+
 # the stride-2 weight gradient on the f16 MFMA (csrc/sr3d_hwgrad_s2.hip; fine row length a multiple of 16): odd and even
 # z / y extents, 64-row and 32-row workgroups, a 2-row last block, a mask slice, 17 channels (a second, almost empty
 # 16-channel block), two dY slices (gated), several x segments, batch 2 -- against fp64, and bit-reproducible
