@@ -77,7 +77,8 @@ __device__ __forceinline__ void split_piece(const float* v, const int st, const 
 // rows of 16 lanes (quad swaps, half-row mirror, row mirror) and four lane reads: vector-ALU only.  (__shfl_xor is a
 // ds_bpermute per step: six dependent trips through the LDS pipe, ~700 cycles in front of a barrier.)
 __device__ __forceinline__ float split_wave_max(float m) {
-#define SR3D_DPP_MAX(ctrl) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), ctrl, 0xf, 0xf, false)))
+// (old = the value itself: every lane has a valid source in these four patterns, and a constant would cost a v_mov per step)
+#define SR3D_DPP_MAX(ctrl) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), ctrl, 0xf, 0xf, false)))
   SR3D_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
   SR3D_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
   SR3D_DPP_MAX(0x141);   // row_half_mirror
