@@ -10,8 +10,8 @@
 //             MODE 1: the chunk loop runs over (class, 16 channels); a chunk has (1+pz)(1+py) phases of (1+px) taps.
 //   gradient  dx[2i + q] = sum over the taps that reach parity q: even: k = 1 from dy[i]; odd: k = 0 from dy[i + 1]
 //             and k = 2 from dy[i].  MODE 2: one launch, blockIdx.z = output class; chunks run over 16 dy channels.
-// The halo of a 2 x 4 x 32 tile is then 3 x 5 x 33 voxels per class in the stride-1 kernel's LDS layout (same
-// pitches), 40 % of which the range-checked buffer loads skip without traffic.
+// The halo of a 2 x 4 x 32 tile is then 3 x 5 x 33 voxels per class, stored with exactly those pitches (32 KB as split fp16),
+// 40 % of which the range-checked buffer loads skip without traffic.
 //
 // Per chunk only 12 .. 96 MFMAs per wave stand against the staging of 16 x 495 values, so the pipeline is simpler
 // than at stride 1: the halo refill is not overlapped inside a workgroup; the second workgroup of the CU covers it.
@@ -25,10 +25,13 @@ namespace {
 
 constexpr int HKC = 16;
 constexpr int S2FLIP_SH = 2;                   // the packed weights and the accumulators change sign every 4 virtual chunks
-constexpr int HHY = 6, HHX = 34;               // LDS pitches of sr3d_hconv.hip; used region 3 x 5 x 33
+// LDS pitches = the used region, 3 x 5 x 33 voxels per plane (the first version kept the 4 x 6 x 34 pitches of sr3d_hconv.hip:
+// 56 KB of halo for 32 KB of data and two workgroups per CU; with tight planes a workgroup takes 48 KB and THREE share
+// a CU -- this kernel lives on the overlap between workgroups, see the header -- and a chunk is staged in 4 rounds instead of 5)
+constexpr int HHY = 5, HHX = 33;
 constexpr int UZ = 3, UY = 5, UX = 33;
-constexpr int HNR = 5;                         // staging rounds: voxel indices < 3 * 6 * 34 = 612 <= 10 * 64
-constexpr int HVOX = 816, HVP = 896;           // plane geometry of sr3d_hconv.hip (kept: same bank behaviour)
+constexpr int HNR = 4;                         // staging rounds: voxel indices < 3 * 5 * 33 = 495 <= 8 * 64
+constexpr int HVOX = 495, HVP = 512;           // voxels of a plane, padded (the wave maxima are exchanged in the padding of plane 0)
 constexpr int HPLANE = HVP * 16;
 constexpr int HBYTES = 4 * HPLANE;
 constexpr int HNT = 256;
@@ -39,7 +42,7 @@ struct SGeo {
   static constexpr int HB = NP * 2 * HPLANE;
   static constexpr size_t LDS = HB + 2 * (size_t)WBUF;
 };
-static_assert(2 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
+static_assert(3 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: three workgroups per CU");
 
 // halo coordinate of local tap i in a dimension of parity `par` (host and device)
 //   MODE 1 (forward):  even: k = 1 at h = 1;  odd: i = 0 -> k = 0 at h = 0, i = 1 -> k = 2 at h = 1   (halo origin o0 - 1)
@@ -53,8 +56,9 @@ __host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
 // vector-memory instructions (~22 cycles of the texture path per wave instruction: 320 per chunk pair of a CU against
 // 2600 cycles of MFMAs); a lane then holds 4 voxels x 4 channels and writes 8-byte half pieces.
 template <int RT, int MODE, bool BF, bool QD = false>
-__global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params p) {
+__global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hconv_s2_kernel(const SrHconvS2Params p) {   // (that one form needs 219 VGPRs)
   static_assert(!QD || (MODE == 2 && !BF), "quad loads: the fp32 input gradient");
+  static_assert(HNR == 4, "the counted wait behind phase 0 assumes 8 * HNR = 32 raw-row loads");
   using G = SGeo<RT, BF>;
   constexpr int NP = G::NP;
   constexpr int ESZ = BF ? 2 : 4;              // bytes per activation element
@@ -286,13 +290,15 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
 #pragma unroll
         for (int c = 0; c < 4; c++)
           pk[c] = __builtin_bit_cast(unsigned, raw[r][2 * c]) | (__builtin_bit_cast(unsigned, raw[r][2 * c + 1]) << 16);
-        *reinterpret_cast<u32x4*>(Hs + sh * HPLANE + swr[r]) = pk;
+        if (swr[r] < HVOX * 16) *reinterpret_cast<u32x4*>(Hs + sh * HPLANE + swr[r]) = pk;
         continue;
       }
       h8 hi, lo;
       split_piece(&raw[r][0], 1, in_mult, hi, lo);
-      *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;   // (rounds 0..4 stay below voxel 640: no slot there)
-      *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
+      if (swr[r] < HVOX * 16) {   // (the padding behind the 495 voxels holds the exchange slots)
+        *reinterpret_cast<h8*>(Hs + (0 * 2 + sh) * HPLANE + swr[r]) = hi;
+        *reinterpret_cast<h8*>(Hs + (1 * 2 + sh) * HPLANE + swr[r]) = lo;
+      }
     }
   };
 
@@ -355,34 +361,31 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
       if (ph == 0) load_raw(vc + 1, kcls_n, cc_n);
       const int iz = ph >> py, iy = ph & py;     // ph = iz * ny + iy with ny = 1 + py
       const unsigned char* Hk = Hs + ((tap_h(MODE, pz, iz) * HHY + tap_h(MODE, py, iy)) * HHX) * 16;
-      h8 fa[2][NP][RT], fb[2][NP][2];   // [tap][part][row tile], [tap][part][voxel row]
+      // one x tap at a time (fragments of both taps in registers at once were 64 VGPRs: 194 in all, two waves per SIMD; with 32
+      // the kernel fits three)
 #pragma unroll
       for (int ix = 0; ix < 2; ix++) {
         if (ix < nxp) {
+          h8 fa[NP][RT], fb[NP][2];   // [part][row tile], [part][voxel row]
           const int hx = tap_h(MODE, px, ix);
 #pragma unroll
           for (int part = 0; part < NP; part++) {
 #pragma unroll
-            for (int i = 0; i < RT; i++) fa[ix][part][i] = *reinterpret_cast<const h8*>(W + ((ix * NP + part) * RT + i) * 1024);
+            for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + ((ix * NP + part) * RT + i) * 1024);
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[ix][part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + hx * 16);
+            for (int j = 0; j < 2; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + hx * 16);
           }
-        }
-      }
-#pragma unroll
-      for (int ix = 0; ix < 2; ix++) {
-        if (ix < nxp) {
 #pragma unroll
           for (int i = 0; i < RT; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
               if constexpr (BF) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[ix][0][i]), __builtin_bit_cast(bf8, fb[ix][0][j]),
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
                                                                    acc[i][j], 0, 0, 0);
               } else {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][NP - 1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][NP - 1][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ix][0][i], fb[ix][0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[NP - 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[NP - 1][i], fb[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
               }
             }
         }
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_kernel(const SrHconvS2Params 
         if constexpr (QD)
           asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         else
-          asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
