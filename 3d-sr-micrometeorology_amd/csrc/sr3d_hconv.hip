@@ -48,6 +48,9 @@
 #ifndef HCONV_NWB_F32
 #define HCONV_NWB_F32 2
 #endif
+#ifndef HCONV_NWB_BF
+#define HCONV_NWB_BF 3
+#endif
 #ifndef HCONV_ABL
 #define HCONV_ABL 0
 #endif
@@ -79,7 +82,10 @@ struct HGeo {
   // loads of the next chunk issued in phase 0, and two phases of distance leave those in flight one phase longer.  No gain
   // (up1 forward 42.1 vs 42.5 ms, profiles/r03f_layers_hconv_weight_buffers.log): the loads cost issue slots, not latency.
   // -DHCONV_NWB_F32=3 builds it.)
-  static constexpr int NWB = BF ? 4 : HCONV_NWB_F32;
+  // (bf16, end of round 3: THREE buffers, two phases ahead -- 52 KB per workgroup, and with 168 VGPRs three workgroups share
+  // a CU instead of two: the bf16 form is bound by synchronisation around short MFMA bursts, and like the stride-2 kernel it
+  // lives on the overlap between workgroups)
+  static constexpr int NWB = BF ? HCONV_NWB_BF : HCONV_NWB_F32;
   // Tap pairs per phase (= per barrier, per weight DMA, per wait).  bf16: TWO -- with 16 MFMAs per phase the ~45 scalar and
   // ~40 vector bookkeeping instructions of a phase and its barrier were 3 + 2.4 per MFMA and the matrix pipe stood at 35 %
   // (profiles/r03d_pmc_instruction_mix_up1_bf16.json; weight DMA distance, halo double-buffering and wider halo loads had
@@ -95,6 +101,7 @@ struct HGeo {
   static constexpr size_t LDS = HBUF * (size_t)HB + NWB * (size_t)WPH;
 };
 static_assert(2 * HGeo<2>::LDS <= 160 * 1024, "LDS budget: two workgroups per CU");
+static_assert(HCONV_NWB_BF != 3 || 3 * HGeo<2, true>::LDS <= 160 * 1024, "LDS budget: three bf16 workgroups per CU");
 
 
 
@@ -131,7 +138,7 @@ __device__ __forceinline__ void hconv_wait_vm(const int n) {
 // raw-row loads (everything else kept) ran 20 % shorter, and more prefetch distance did not help: the loads cost
 // instruction slots of the texture path, not latency (profiles/r03e_ablation_hconv_kernel_fp32.log).
 template <int RT, bool BF, bool PAIR>
-__global__ __launch_bounds__(HNT, 2) void hconv_kernel(const SrHconvParams p) {
+__global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_kernel(const SrHconvParams p) {
   using G = HGeo<RT, BF>;
   constexpr bool BPAIR = BF && PAIR, QUAD = !BF && PAIR;
   constexpr int NR = BPAIR ? 4 : QUAD ? 2 : HNR;   // staging rounds
