@@ -284,7 +284,9 @@ __global__ __launch_bounds__(WNT) void hwgrad_kernel(const HwParams p) {
       const int t = t0 + u;
       if (t >= yb) break;
       // (staging AFTER the step's MFMAs instead of before them -- legal, the rows go to slots row t does not read -- was
-      // tried: no change in the split form, 30 % slower in the bf16 form, profiles/r03d_ab_hwgrad_late_staging.log)
+      // tried: no change in the split form, 30 % slower in the bf16 form, profiles/r03d_ab_hwgrad_late_staging.log; STAGGERED --
+      // the X stagers before, the dY stagers after their MFMAs, two early waves and a late one on every SIMD -- 6 % / 10 %
+      // slower, profiles/r03f_ab_hwgrad_staggered_staging.log)
       if (t > ya - 4) {
         const long long rr = plane * p.Y + (t + 1);
         write_piece(u, (t + 2) & 3, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
