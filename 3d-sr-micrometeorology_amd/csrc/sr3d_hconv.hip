@@ -48,6 +48,9 @@
 #ifndef HCONV_NWB_F32
 #define HCONV_NWB_F32 2
 #endif
+#ifndef HCONV_SETPRIO
+#define HCONV_SETPRIO 0
+#endif
 #ifndef HCONV_NWB_BF
 #define HCONV_NWB_BF 3
 #endif
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
             }
           }
         }
+        if constexpr (HCONV_SETPRIO != 0) __builtin_amdgcn_s_setprio(1);   // (the MFMA burst ahead of the other workgroup's vector work)
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
             }
           }
         }
+        if constexpr (HCONV_SETPRIO != 0) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
       }   // sub
