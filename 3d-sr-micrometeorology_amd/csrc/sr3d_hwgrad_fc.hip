@@ -28,7 +28,10 @@ constexpr int FXROW = 2 * 16 * FPITCH;         // one X row: [part][column (c, k
 constexpr int FXBYTES = 12 * FXROW;            // 3 planes x 4 y slots
 constexpr int FDROW = 2 * FNB * FPITCH;        // one dY row: [part][n][PITCH]
 constexpr size_t FLDS = FXBYTES + 2 * (size_t)FDROW;
-constexpr int FNS = 3;                         // steps the loads run ahead
+#ifndef HWGRAD_FC_NS
+#define HWGRAD_FC_NS 3
+#endif
+constexpr int FNS = HWGRAD_FC_NS;                         // steps the loads run ahead
 static_assert(2 * FLDS <= 160 * 1024, "two workgroups per CU");
 
 __host__ __device__ inline int fc_scale_exp_of(float amax) {
