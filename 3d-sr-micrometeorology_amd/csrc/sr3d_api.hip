@@ -3,6 +3,7 @@
 
 #include <limits.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -29,6 +30,29 @@ int sr3d_make_cat(const sr3d_slice_t* s, int n, long long vox, int expect_channe
   out->n = n;
   SR3D_CHECK(c == expect_channels, SR3D_E_ARG, "%s: slices hold %d channels, the layer expects %d", what, c,
              expect_channels);
+  return SR3D_OK;
+}
+
+// ---- zeroing of the few control words (maxima, scale headers) in front of a launch ---------------------------------
+// A KERNEL, not hipMemsetAsync: inside a captured training step (src/graph.py) a memset becomes a memset NODE of the
+// hipGraph, and on this runtime (ROCm 7.2) the replay does not keep such a node ordered against the kernel nodes around
+// it -- the maxima words of the split-f16 kernels were cleared too early or too late.  Kernel nodes
+// of one captured stream replay in order.  SR3D_DEBUG_MEMSET_NODE=1 brings the memset back (tests/test_gpu_graph.py shows
+// the divergence with it).
+namespace {
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+int sr3d_zero_words(void* p, int nwords, hipStream_t st) {
+  static const bool memset_node = getenv("SR3D_DEBUG_MEMSET_NODE") != nullptr && atoi(getenv("SR3D_DEBUG_MEMSET_NODE")) != 0;
+  if (memset_node) {
+    SR3D_HIP(hipMemsetAsync(p, 0, (size_t)nwords * 4, st));
+    return SR3D_OK;
+  }
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, (unsigned*)p, nwords);
+  SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }
 

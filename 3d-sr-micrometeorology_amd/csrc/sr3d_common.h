@@ -27,6 +27,8 @@ struct ChanCat {
 };
 
 void sr3d_set_error(const char* fmt, ...);
+// p[0 .. nwords) = 0 by a kernel launch on `st` (never a memset node inside a captured graph: sr3d_api.hip)
+int sr3d_zero_words(void* p, int nwords, hipStream_t st);
 
 
 

@@ -641,7 +641,7 @@ int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, c
   SrProfScope prof(SR3D_PROF_PACK, (bf ? 3.0 : 4.0) * (double)rows * K * 27 * 2, st);
   const long long nw = (long long)Cout * Cin * 27;
   if (!bf) {
-    SR3D_HIP(hipMemsetAsync(hdr, 0, 64, st));
+    if (int rc = sr3d_zero_words(hdr, 16, st)) return rc;
     if (int rc = sr3d_absmax_launch(w1, nw, hdr, st)) return rc;
     if (w2 != nullptr)
       if (int rc = sr3d_absmax_launch(w2, nw, hdr, st)) return rc;

@@ -488,7 +488,7 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
   unsigned* amax = (unsigned*)ws;
   const long long vox = (long long)d->Z * d->Y * d->X;
   if (!bf) {   // (bf16 operands are not scaled: no maxima pass)
-    SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
+    if (int rc = sr3d_zero_words(amax, 64, st)) return rc;
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     if (x_absmax == nullptr)
       for (int i = 0; i < x.n; i++)

@@ -329,7 +329,7 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& d
   const FcPlan g = fc_plan(d, n_total);
   unsigned* amax = (unsigned*)ws;
   {
-    SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
+    if (int rc = sr3d_zero_words(amax, 64, st)) return rc;
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     if (x_absmax == nullptr)
       for (int i = 0; i < x.n; i++)

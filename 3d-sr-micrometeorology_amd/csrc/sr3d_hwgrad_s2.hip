@@ -416,7 +416,7 @@ int sr3d_hwgrad_s2(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& d
   const bool bf = d->dtype == SR3D_DTYPE_BF16;
   unsigned* amax = (unsigned*)ws;
   if (!bf) {
-    SR3D_HIP(hipMemsetAsync(amax, 0, 256, st));
+    if (int rc = sr3d_zero_words(amax, 64, st)) return rc;
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     if (x_absmax == nullptr)
       for (int i = 0; i < x.n; i++)

@@ -76,7 +76,8 @@ def train_and_validate(rank: int, world_size: int, config: dict, weight_path: st
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         init_method = None
     else:
-        init_method = f"file://{port}"
+        # absolute: "file://out/x" would parse as netloc "out" + path "/x" (a relative --result_root), and torch only uses the path
+        init_method = "file://" + os.path.abspath(str(port))
     # RCCL ("nccl" under PyTorch-ROCm), one GPU per rank.  SR3D_DIST_BACKEND=gloo keeps the ranks on the CPU: the
     # multi-process rehearsal of this function's control flow (tests/test_dist_paths_gloo.py, with a stub engine -- the
     # HIP engine itself has no CPU path and raises).
@@ -213,7 +214,7 @@ def main():
         mlflow = None
     try:
         t0 = time.time()
-        rendezvous = os.path.join(result_dir, ".rendezvous")
+        rendezvous = os.path.abspath(os.path.join(result_dir, ".rendezvous"))
         if os.path.exists(rendezvous):
             os.remove(rendezvous)
         mp.spawn(train_and_validate, args=(args.world_size, config, weight_path, history_path, args.data_root,

@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libsr3d.so is linked with -fvisibility=hidden: what this header declares is ALL the library exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SR3D_VERSION 100 /* 0.1.0 */
 
@@ -281,6 +285,9 @@ enum {
 int sr3d_profile_enable(int on);
 int sr3d_profile_read(int kernel_id, double* ms, double* work, long long* launches);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,11 @@ def test_library_exports_every_declared_symbol(eng):
     # ... and the Python binding knows all of them
     assert set(names) == set(eng._lib.SYMBOLS.keys())
     assert lib.sr3d_version() == 100
+    # ... and NOTHING else is exported (the library is linked with -fvisibility=hidden): the boundary is the header
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", eng._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-2] in ("T", "t", "W", "w", "D", "d")}
+    assert exported == set(names), f"not in include/sr3d.h: {sorted(exported - set(names))}"
 
 
 def test_argument_errors_are_reported_not_crashes(eng):

@@ -52,7 +52,9 @@ def _bench_worker(rank, world, port, q):
     flat = stub.LAST_OPT.flat_param.clone()
     got = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(got, flat)
-    q.put((rank, m["elapsed"], m["voxels_per_step"], m["loss"], [g.clone() for g in got]))
+    # numpy arrays travel through the queue BY VALUE (pickled); a torch tensor would travel as a shared-memory handle
+    # that the parent can only open while this process is still alive -- an EOFError once in a few runs
+    q.put((rank, m["elapsed"], m["voxels_per_step"], m["loss"], [g.numpy().copy() for g in got]))
     dist.destroy_process_group()
 
 
@@ -92,6 +94,7 @@ def test_bench_measure_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, e0, v0, l0, g0), (_, e1, v1, l1, g1) = out
+    g0, g1 = [torch.from_numpy(a) for a in g0], [torch.from_numpy(a) for a in g1]
     assert e0 == e1 and e0 > 0                               # MAX over ranks: both report the same elapsed time
     hr = [4 * v for v in LR_GRID]
     assert v0 == v1 == world * BATCH * hr[0] * hr[1] * hr[2]    # whole-job voxels per step
@@ -125,8 +128,8 @@ def _train_worker(rank, world, config, weight_path, history_path, data_root, por
     torch.save(stub.LAST_OPT.flat_param, os.path.join(os.path.dirname(weight_path), f"flat_rank{rank}.pt"))
 
 
-@pytest.mark.parametrize("variant", ["plain", "gradnorm"])
-def test_train_and_validate_two_ranks_gloo(tmp_path, variant):
+@pytest.mark.parametrize("variant", ["plain", "gradnorm", "relative_result_root"])
+def test_train_and_validate_two_ranks_gloo(tmp_path, variant, monkeypatch):
     from data_fixture import write_synthetic_tree
     data_root = write_synthetic_tree(tmp_path / "d", HR=(8, 16, 16), days=6)
     config = {
@@ -143,9 +146,12 @@ def test_train_and_validate_two_ranks_gloo(tmp_path, variant):
     res = tmp_path / "res"
     res.mkdir()
     (res / "config.yml").write_text(yaml.safe_dump(config))
-    weight_path, history_path = str(res / "weights.pth"), str(res / "learning_history.csv")
+    weight_path, history_path, rendezvous = str(res / "weights.pth"), str(res / "learning_history.csv"), str(res / ".rendezvous")
+    if variant == "relative_result_root":     # `--result_root out`: "file://res/.rendezvous" would be host "res", path "/.rendezvous"
+        monkeypatch.chdir(tmp_path)
+        weight_path, history_path, rendezvous = "res/weights.pth", "res/learning_history.csv", "res/.rendezvous"
     world = 2
-    mp.spawn(_train_worker, args=(world, config, weight_path, history_path, str(data_root), str(res / ".rendezvous")),
+    mp.spawn(_train_worker, args=(world, config, weight_path, history_path, str(data_root), rendezvous),
              nprocs=world, join=True)      # raises if a rank fails or hangs up (file rendezvous, as train_model.main uses)
     sd = torch.load(weight_path)
     assert set(sd) == {"body.weight", "body.bias", "last.weight", "last.bias"}

@@ -1,4 +1,6 @@
 """hipGraph-captured training step (src/graph.py) == the eager step, bit for bit, step after step."""
+import os
+
 import pytest
 import torch
 
@@ -50,6 +52,49 @@ def test_graphed_steps_equal_eager_steps(eng, loss_name):
     assert torch.equal(o1.exp_avg, o2.exp_avg) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
     with pytest.raises(ValueError):
         step(batches[0][0][:1], batches[0][1][:1], batches[0][2][:1])
+
+
+def _dirty_allocator(gb=4):
+    """fill and free a few GB with a NaN bit pattern: blocks the caching allocator recycles, and pages the driver hands
+    out again after an `empty_cache()`, are dirty -- a kernel that reads a workspace it did not write cannot pass"""
+    t = torch.full((gb * (1 << 28),), float("nan"), device=DEV)
+    torch.cuda.synchronize()
+    del t
+
+
+def test_default_width_graphed_steps_equal_eager_steps_on_dirty_memory(eng):
+    """The captured step at default.yml widths on a grid where the DEFAULT dispatch takes the split-f16 kernels
+    (hconv / hconv_s2 / hwgrad / hwgrad_s2 / hwgrad_fc: HR 32x64x64 = BASELINE configs[0]'s volume), i.e. the launch
+    sequences with maxima words, scale headers and slab workspaces that the tiny model above never reaches.
+
+    Round 3's bench showed the fp32 replay leaving the eager trajectory at 80x320x320 (loss 0.350 / 0.267 / 0.264 against
+    0.3371 after the same 7 steps, different from run to run; the bf16 replay, which has no maxima, was bit-reproducible).
+    Cause: the library cleared its maxima words / scale headers with hipMemsetAsync; captured, those become
+    memset NODES, and the replay did not keep them ordered against the kernel nodes around them.  They are kernel launches
+    now.  (SR3D_DEBUG_MEMSET_NODE=1 restores the memsets: tools/graph_diag.py, profiles/r04_graph_diag_*.log.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_config, synthetic_batch
+    cfg = make_config("l1")
+    x, b, y = synthetic_batch(1, (32, 64, 64), 4, 1234, DEV)
+    steps = 3
+
+    def fresh(capturable):
+        torch.manual_seed(42)
+        model = eng.make_model(cfg).to(DEV)
+        return model, eng.make_loss(cfg), eng.FlatAdam(model.parameters(), lr=1e-4, capturable=capturable)
+
+    m1, lf1, o1 = fresh(False)
+    _dirty_allocator()
+    eager = [_eager(m1, lf1, o1, x, b, y) for _ in range(steps)]
+    m2, lf2, o2 = fresh(True)
+    _dirty_allocator()
+    step = eng.GraphedTrainStep(m2, lf2, o2, x, b, y)
+    _dirty_allocator()
+    graphed = [float(step(x, b, y)) for _ in range(steps)]
+    assert graphed == eager
+    assert torch.equal(o1.flat_param, o2.flat_param)
+    assert torch.equal(o1.exp_avg, o2.exp_avg) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
 
 
 def test_capturable_adam_matches_host_counter(eng):
