@@ -44,6 +44,9 @@ class GradAllReducer:
         for p in self.params:
             self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
         self.comm_stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # False: the hooks launch nothing and finish() reduces every bucket, in the order backward produced them -- a
+        # backward that is being captured into a hipGraph WITHOUT its collectives (src/graph.py, comm="split")
+        self.hooks_enabled = True
         self.reset()
 
     def reset(self) -> None:
@@ -65,6 +68,8 @@ class GradAllReducer:
             b["work"] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p: torch.nn.Parameter) -> None:
+        if not self.hooks_enabled:
+            return
         b = self.buckets[p._sr3d_bucket]
         b["pending"] -= 1
         if b["pending"] == 0:

@@ -46,26 +46,50 @@ def _device_batches(dataloader, device, num_loops: int = 1):
 class LazyGraphedStep:
     """Engine extension (no reference counterpart): the training step as a hipGraph replay (src/graph.py) inside the
     reference's loops.  Captured on the first batch; a batch of another shape (the last, partial one of an epoch) runs
-    eagerly.  Needs ``FlatAdam(capturable=True)``, one GPU, no GradNorm."""
+    eagerly.  Needs ``FlatAdam(capturable=True)``, no GradNorm; ``reducer`` = the data-parallel gradient averaging that
+    belongs to the step (every rank then captures, replays and falls back in lockstep: same shapes on every rank)."""
 
-    def __init__(self, model, loss_fn, optimizer):
+    def __init__(self, model, loss_fn, optimizer, reducer=None, comm=None):
         self.model, self.loss_fn, self.optimizer, self.graphed = model, loss_fn, optimizer, None
-        self.failed = False     # the capture raised once: every step runs eagerly from then on
+        self.reducer, self.comm = reducer, comm
+        self.failed = False     # the capture was invalidated once: every step runs eagerly from then on
+
+    @staticmethod
+    def _is_capture_invalidation(e: BaseException) -> bool:
+        """a capture-unsafe call somewhere (another library, another thread) -- as opposed to an engine error, an
+        out-of-memory condition or a sticky HIP error, which must not be downgraded to a warning"""
+        if isinstance(e, torch.cuda.OutOfMemoryError):
+            return False
+        msg = str(e).lower()
+        return isinstance(e, RuntimeError) and ("captur" in msg or "graph" in msg) and "out of memory" not in msg
 
     def _capture(self, Xs, bs, ys):
         from .graph import GraphedTrainStep
         opt = self.optimizer
-        keep = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev)]
+        state = [t for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, getattr(opt, "_step_dev", None)) if t is not None]
+        keep = [t.clone() for t in state]
+        ok = False
         try:
-            self.graphed = GraphedTrainStep(self.model, self.loss_fn, opt, Xs, bs, ys)
-        except Exception as e:   # a capture-unsafe call somewhere (another library, another thread): train eagerly
+            self.graphed = GraphedTrainStep(self.model, self.loss_fn, opt, Xs, bs, ys, reducer=self.reducer, comm=self.comm)
+            ok = True
+            logger.info(f"training step captured into a hipGraph (batch {tuple(Xs.shape)}, gradient averaging: "
+                        f"{self.graphed.comm or 'none'})")
+        except Exception as e:
+            if not self._is_capture_invalidation(e):
+                raise
             logger.warning(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                            "continuing with eager steps")
-            torch.cuda.synchronize()
-            with torch.no_grad():   # the warm-up / aborted capture must leave no trace in the optimizer state
-                for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt._step_dev), keep):
-                    dst.copy_(src)
             self.failed = True
+        finally:
+            if not ok:      # the warm-up / aborted capture must leave no trace in the optimizer state
+                if Xs.is_cuda:
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:       # noqa: BLE001  (a sticky error: the original exception is the one to report)
+                        pass
+                with torch.no_grad():
+                    for dst, src in zip(state, keep):
+                        dst.copy_(src)
 
     def __call__(self, Xs, bs, ys):
         if self.graphed is None and not self.failed:
@@ -73,7 +97,7 @@ class LazyGraphedStep:
         g = self.graphed
         if g is not None and Xs.shape == g.x.shape and bs.shape == g.b.shape and ys.shape == g.y.shape:
             return g(Xs, bs, ys).clone()        # (the graph's loss buffer is overwritten by the next replay)
-        return _train_step(self.model, self.loss_fn, self.optimizer, Xs, bs, ys).detach()
+        return _train_step(self.model, self.loss_fn, self.optimizer, Xs, bs, ys, reducer=self.reducer).detach()
 
 
 def _last_params(model):

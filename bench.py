@@ -103,10 +103,11 @@ def cpu_baseline(cfg, budget_s=20.0):
     from oracle import ref_cpu as R
     cores = host_cores()
     torch.set_num_threads(cores)
-    # BASELINE.json configs[0]: a single 32x32x16 LR volume -> 2x (num_x2upsample = 1), i.e. HR 32x64x64
+    # the GPU workload's own model (4x, default.yml widths) and loss on a volume the CPU finishes in about a second:
+    # HR 32x64x64 (the HR volume of BASELINE.json configs[0], and default.yml's training crop) from LR 8x16x16
     cfg = json.loads(json.dumps(cfg))
-    cfg["model"]["num_x2upsample"] = 1
-    hr, scale = (32, 64, 64), 2
+    scale = 2 ** cfg["model"]["num_x2upsample"]
+    hr = (32, 64, 64)
     sd = R.random_state_dict(cfg["model"], seed=42)
     opt = R.AdamState(sd, lr=cfg["train"]["lr"])
     x, b, y = synthetic_batch(1, hr, scale, 1234, "cpu")
@@ -122,10 +123,11 @@ def cpu_baseline(cfg, budget_s=20.0):
     sec = sum(times) / len(times)
     vox = hr[0] * hr[1] * hr[2]
     return {"value": vox / sec, "unit": "HR voxels/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"{len(times)} full training steps (fwd+loss+bwd+Adam, same model and loss) of the CPU oracle "
-                      f"on BASELINE configs[0]'s volume: LR {hr[0] // scale}x{hr[1] // scale}x{hr[2] // scale} -> 2x -> HR "
-                      f"{hr[0]}x{hr[1]}x{hr[2]}, batch 1, {sec:.2f} s/step; the 80x320x320 "
-                      f"volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
+            "sample": f"{len(times)} full training steps (fwd+loss+bwd+Adam) of the CPU oracle: the SAME model ({scale}x SR, "
+                      f"default.yml widths), loss and optimizer as the GPU line, on a smaller volume -- LR "
+                      f"{hr[0] // scale}x{hr[1] // scale}x{hr[2] // scale} -> HR {hr[0]}x{hr[1]}x{hr[2]} (131,072 HR voxels, the HR "
+                      f"volume of BASELINE configs[0] and default.yml's training crop), batch 1, {sec:.2f} s/step; the "
+                      f"80x320x320 volume of the GPU workload needs ~35 GB and minutes per step on CPU"}
 
 
 def read_profile(L):
@@ -157,8 +159,6 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     loss_fn = sr3d_amd.make_loss(cfg)
     opt = sr3d_amd.FlatAdam(model.parameters(), lr=cfg["train"]["lr"], capturable=graph)
     reducer = None
-    if graph and use_dist:
-        sys.exit("bench.py --graph captures the single-GPU step; the gradient all-reduce stays on the eager path")
     if use_dist:
         reducer = sr3d_amd.GradAllReducer(opt.params, opt.flat_grad, opt.offsets)
         reducer.broadcast_parameters(opt.flat_param)
@@ -176,8 +176,9 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
         opt.step()
         return loss
 
-    if graph:      # the whole step captured once into a hipGraph; every step below is one replay
-        gstep = sr3d_amd.GraphedTrainStep(model, loss_fn, opt, x, b, y)
+    if graph:      # the whole step captured once into a hipGraph; every step below is one replay (+ with N > 1 the bucket
+        #            all-reduces: eager between the captured backward and Adam, or captured too -- src/graph.py)
+        gstep = sr3d_amd.GraphedTrainStep(model, loss_fn, opt, x, b, y, reducer=reducer)
 
         def step():  # noqa: F811
             return gstep(x, b, y)
@@ -192,8 +193,13 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
         if on_gpu:
             torch.cuda.synchronize()
 
+    losses = []                         # the loss of every step (device scalars; read after the timed region)
+
+    def keep(loss):
+        losses.append(loss.detach().clone() if graph else loss.detach())
+
     for _ in range(warmup):
-        step()
+        keep(step())
     fence()
     if not graph:                       # (event records cannot be part of a captured step)
         # dominant family only; the event pool is created here, outside the timed region
@@ -203,9 +209,11 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
+        keep(loss)
     fence()
     elapsed = time.perf_counter() - t0
     last_loss = float(loss.detach())
+    losses = [float(v) for v in losses]
 
     prof = read_profile(L)              # dominant family, timed steps
     L.profile_enable(False)
@@ -227,7 +235,7 @@ def measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, lr_grid, 
     if on_gpu:
         torch.cuda.empty_cache()
     return {"elapsed": float(t.item()), "prof": prof, "breakdown": breakdown, "breakdown_steps": breakdown_steps,
-            "loss": last_loss, "hr": hr, "cfg": cfg, "peak_mem_gb": (torch.cuda.max_memory_allocated(dev) / 2 ** 30 if on_gpu else 0.0),
+            "loss": last_loss, "losses": losses, "hr": hr, "cfg": cfg, "peak_mem_gb": (torch.cuda.max_memory_allocated(dev) / 2 ** 30 if on_gpu else 0.0),
             "voxels_per_step": world * batch * hr[0] * hr[1] * hr[2]}
 
 
@@ -356,21 +364,21 @@ def main():
         if split:
             kernel_desc = ("stride-1 conv forward + input gradient on hconv_kernel: direct implicit GEMM on "
                            "v_mfma_f32_16x16x32_f16, fp32 operands split into two fp16 halves (3 products), fp32 accumulate")
-            note = ("achieved = f16 MFMA FLOPs the kernel EXECUTES per second = 3 x algorithmic FLOPs of the 3x3x3 "
-                    "convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d); channel padding to 16 not counted) / kernel "
-                    "time from HIP events, over the kernel's launches of >= 448 workgroups (they fill the chip; the launches on "
+            note = ("achieved = ALGORITHMIC FLOPs of the 3x3x3 convolution per second (2*27*Cin*Cout per output voxel, SURVEY "
+                    "8(d)) / kernel time from HIP events; executed_tflops = 3 x that, the f16 MFMA FLOPs the split scheme "
+                    "really issues (channel padding to 16 not counted); over the kernel's launches of >= 448 workgroups (they fill the chip; the launches on "
                     "the small grids of U-Net levels 3-4 are listed as conv_kernels.hconv_small); peak = dense f16 MFMA at 2.4 "
                     "GHz.  The f16 MFMA is POWER-bound on this part: "
                     f"tools/mfma_rate.hip sustains {F16_MFMA_SUSTAINED_TFLOPS:.0f} TFLOP/s with the kernel's MFMA shape, 16x16x32 "
-                    "(register operands only, 100 ms, clock settling at 1.89 GHz; 1674 with 32x32x16) -- frac_of_sustained is "
+                    "(register operands only, 100 ms, clock settling at 1.89 GHz; 1674 with 32x32x16) -- frac_executed_of_sustained is "
                     "against that")
         else:
             kernel_desc = ("stride-1 conv forward + input gradient (wino_kernel: Winograd F(2x2,3x3) x 3 z-taps on "
                            "v_mfma_f32_32x32x2_f32; direct igemm_kernel with SR3D_WINOGRAD=0)")
-            note = ("achieved = fp32 MFMA FLOPs the kernel EXECUTES per second = algorithmic FLOPs of the "
-                    "3x3x3 convolution (2*27*Cin*Cout per output voxel, SURVEY 8(d)) / 2.25 (Winograd "
-                    "F(2x2,3x3) in (y,x) needs 48 instead of 108 products per 2x2x1 outputs) / kernel time "
-                    "from HIP events; frac = matrix-pipe utilisation against the fp32 MFMA peak")
+            note = ("achieved = ALGORITHMIC FLOPs of the 3x3x3 convolution per second (2*27*Cin*Cout per output voxel, "
+                    "SURVEY 8(d)) / kernel time from HIP events; executed_tflops = that / 2.25 (Winograd F(2x2,3x3) in (y,x) "
+                    "needs 48 instead of 108 products per 2x2x1 outputs); frac_executed = matrix-pipe utilisation against "
+                    "the fp32 MFMA peak (frac can exceed it: Winograd)")
         # every other family: from the untimed breakdown pass (all launches bracketed; ~4 % slower steps)
         bd, bs = m["breakdown"] or prof, (m["breakdown_steps"] if m["breakdown"] else args.steps)
         conv = {k: {"ms_per_step": bd[k]["ms"] / bs, "launches_per_step": bd[k]["launches"] / bs,
@@ -403,14 +411,15 @@ def main():
                        (" [hipGraph replay]" if args.graph else ""),
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s",
-                         "frac": executed / peak, "frac_algorithmic": algo / peak, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": algo, "peak": peak, "unit": "TFLOP/s",
+                         "frac": algo / peak, "frac_algorithmic": algo / peak, "traffic": traffic,
+                         "executed_tflops": executed, "frac_executed": executed / peak,
                          "kernel": kernel_desc,
                          "note": note,
                          "algorithmic_tflops": algo,
                          "launches_per_step": dom["launches"] / args.steps,
                          "kernel_ms_per_step": dom["ms"] / args.steps,
-                         **({"frac_of_sustained": executed / F16_MFMA_SUSTAINED_TFLOPS} if split else {})},
+                         **({"frac_executed_of_sustained": executed / F16_MFMA_SUSTAINED_TFLOPS} if split else {})},
             "hbm_frac": value / (world * HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL),
             "hbm_note": f"voxels/s against the HBM-only ceiling {HBM_PEAK_GBS * 1e9 / BYTES_PER_VOXEL / 1e6:.0f} M voxels/s/GPU "
                         f"(8 TB/s / {BYTES_PER_VOXEL} B of compulsory activation traffic per voxel); the step is "
@@ -445,10 +454,16 @@ def main():
                                                                             FP32_MFMA_PEAK_TFLOPS if fd["ms"] > 0 else 0.0)}
         if replay is not None:
             n5 = min(args.steps, 5)
+            # the replayed trajectory against the eager one of the headline run, step for step (same seeds, same data):
+            # bit-equal since the control words are zeroed by a kernel (round 3: memset nodes)
+            nr = len(replay["losses"])
+            eager_same = m["losses"][:nr] if len(m["losses"]) >= nr else None
             out["hipgraph_replay"] = {"note": "same workload, the whole step (forward, loss, backward, Adam) captured once with "
                                               "GraphedTrainStep and replayed; ~550 launches per step lose ~20 us each on the eager path",
                                       "value": replay["voxels_per_step"] * n5 / replay["elapsed"], "unit": "HR voxels/s",
-                                      "steps": n5, "warmup": 2, "ms_per_step": replay["elapsed"] / n5 * 1e3, "loss": replay["loss"]}
+                                      "steps": n5, "warmup": 2, "ms_per_step": replay["elapsed"] / n5 * 1e3, "loss": replay["loss"],
+                                      "losses": replay["losses"], "eager_losses_same_steps": eager_same,
+                                      "loss_matches_eager": (eager_same == replay["losses"]) if eager_same is not None else None}
         if bf16_same is not None:
             n5 = min(args.steps, 5)
             bp = bf16_same["prof"]["hconv"]
@@ -459,7 +474,8 @@ def main():
                 "note": ("engine extension `model: {storage_dtype: bf16}`: same model, same shape as the headline; NOT the headline "
                          "(the reference and configs[1] are fp32).  Parity unpinned: the reference has no bf16 path; "
                          "tests/test_gpu_bf16.py holds every kernel to exactness on bf16-representable operands and the whole "
-                         "model to 3e-2 / 8e-2 (prediction / parameter gradients) of the fp32 oracle"),
+                         "model to 1e-2 (prediction, loss) / 5e-2 (parameter gradients, the bf16 run's branch decisions forced "
+                         "into the oracle) of the fp32 oracle"),
                 "value": bf16_same["voxels_per_step"] * n5 / bf16_same["elapsed"], "unit": "HR voxels/s", "steps": n5, "warmup": 1,
                 "ms_per_step": bf16_same["elapsed"] / n5 * 1e3, "loss": bf16_same["loss"], "peak_mem_gb": bf16_same["peak_mem_gb"],
                 "roofline": {"bound": "mfma", "kernel": "hconv_kernel<bf16>: one v_mfma_f32_16x16x32_bf16 per product group "

@@ -16,6 +16,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -104,6 +105,81 @@ def test_bench_measure_two_ranks_gloo():
     assert torch.allclose(g0[0], ref, rtol=1e-5, atol=1e-7), float((g0[0] - ref).abs().max())
 
 
+# ------------------------------------------------------------------------------------------------ graph + reducer
+def _graph_worker(rank, world, port, q):
+    """GraphedTrainStep WITH the gradient reducer (BASELINE configs[4]: "8 GPUs and a captured step"), both ways of
+    composing them, against the eager step with the reducer -- on CPU ranks a "graph" is a recorded callable, so what is
+    rehearsed is the control flow: muted hooks inside segment A, the order and number of collectives, warm-up undone"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import cpu_engine_stub as stub
+    import sr3d_amd
+    cfg = bench.make_config("l1")
+    hr, scale = (8, 16, 16), 4
+    batches = [bench.synthetic_batch(2, hr, scale, 100 * rank + i, "cpu") for i in range(3)]
+
+    def run(mode):
+        torch.manual_seed(42 + (rank if mode == "unsynced_init" else 0))
+        model = stub.make_model(cfg)
+        loss_fn = stub.make_loss(cfg)
+        opt = stub.FlatAdam(model.parameters(), lr=1e-3, capturable=True)
+        red = stub.GradAllReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=1024)
+        red.broadcast_parameters(opt.flat_param)
+        calls = {"n": 0}
+        launch = red._launch
+
+        def counted(b):
+            calls["n"] += 1
+            launch(b)
+        red._launch = counted
+        losses = []
+        if mode == "eager":
+            for x, b, y in batches:
+                loss = loss_fn(model(x, b), y, b)
+                opt.zero_grad()
+                loss.backward()
+                opt.grad_scale = red.finish()
+                opt.step()
+                losses.append(float(loss.detach()))
+        else:
+            g = sr3d_amd.GraphedTrainStep(model, loss_fn, opt, *batches[0], reducer=red, comm=mode)
+            assert opt._host_step == 0                    # the warm-up inside the constructor left no trace
+            calls["n"] = 0
+            losses = [float(g(x, b, y)) for x, b, y in batches]
+        red.remove_hooks()
+        return losses, opt.flat_param.clone().numpy(), calls["n"], len(red.buckets)
+
+    out = {m: run(m) for m in ("eager", "split", "captured")}
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_graphed_step_with_reducer_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        e_loss, e_par, e_calls, nb = out[r]["eager"]
+        assert nb >= 2 and e_calls == 3 * nb                 # one all-reduce per bucket and step
+        for mode in ("split", "captured"):
+            loss, par, calls, _ = out[r][mode]
+            assert loss == e_loss, (mode, loss, e_loss)     # same step, same collectives: bit-equal on every rank
+            assert np.array_equal(par, e_par), mode
+            assert calls == 3 * nb, (mode, calls)
+    assert np.array_equal(out[0]["split"][1], out[1]["split"][1])      # ranks in lockstep
+    assert out[0]["eager"][0] != out[1]["eager"][0]                     # ... on different data
+
+
 # ------------------------------------------------------------------------------------------------ train_model.py
 def _load_train_model():
     spec = importlib.util.spec_from_file_location(
@@ -128,7 +204,7 @@ def _train_worker(rank, world, config, weight_path, history_path, data_root, por
     torch.save(stub.LAST_OPT.flat_param, os.path.join(os.path.dirname(weight_path), f"flat_rank{rank}.pt"))
 
 
-@pytest.mark.parametrize("variant", ["plain", "gradnorm", "relative_result_root"])
+@pytest.mark.parametrize("variant", ["plain", "gradnorm", "relative_result_root", "hip_graph"])
 def test_train_and_validate_two_ranks_gloo(tmp_path, variant, monkeypatch):
     from data_fixture import write_synthetic_tree
     data_root = write_synthetic_tree(tmp_path / "d", HR=(8, 16, 16), days=6)
@@ -143,6 +219,8 @@ def test_train_and_validate_two_ranks_gloo(tmp_path, variant, monkeypatch):
     }
     if variant == "gradnorm":
         config["train"]["grad_norm"] = {"n_tasks": 3, "alpha": 1.5, "lr": 1.0e-2}
+    if variant == "hip_graph":       # the captured step WITH the reducer (split form), inside the reference's epoch loops
+        config["train"]["hip_graph"] = True
     res = tmp_path / "res"
     res.mkdir()
     (res / "config.yml").write_text(yaml.safe_dump(config))
@@ -161,3 +239,6 @@ def test_train_and_validate_two_ranks_gloo(tmp_path, variant, monkeypatch):
     assert torch.equal(flats[0], flats[1])                   # broadcast + averaged gradients: ranks stay in lockstep
     assert "Epoch: 2" in (res / "log.txt").read_text()
     assert (res / "grad_norm_weights_cpu.csv").exists() == (variant == "gradnorm")
+    assert ("training step captured into a hipGraph" in (res / "log.txt").read_text()) == (variant == "hip_graph")
+    if variant == "hip_graph":
+        assert "gradient averaging: split" in (res / "log.txt").read_text()

@@ -141,6 +141,11 @@ def test_whole_model_default_widths(eng, fname):
         rows.append(row)
         if clean and not (min(row["orc32"], row["orc64"]) < TOL and min(row["gold32"], row["gold64"]) < TOL):
             bad.append(row)
+        # ... and a gross-error net under the others: a differing decision moves a gradient by ~ 1 / sqrt(elements of its
+        # activation) (5.6e-3 for one of the 32 k outputs of a level-4 layer), the reference's own fp32-vs-fp64 floor is
+        # the same lottery; a wrong tile or tap that only shows with free decisions would be O(0.1 .. 1)
+        if not clean and min(row["orc32"], row["orc64"]) > max(FREE_LOOSE, 10.0 * row["orc_floor"]):
+            bad.append(row)
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     tag = os.environ.get("SR3D_WINOGRAD", "1") + os.environ.get("SR3D_WINOGRAD_WGRAD", "1") + \
@@ -156,6 +161,7 @@ def test_whole_model_default_widths(eng, fname):
 
 
 EPS32 = 2.0 ** -24
+FREE_LOOSE = 2e-2    # free-running bound for parameters a differing decision can reach (see (3) above)
 KINK_C = 8.0         # differing decisions must have |pre| <= KINK_C * eps * sum|w||x| (worst observed: 2.05; a typical
                      # pre-activation sits at ~3e5 on this scale, so a systematically wrong branch cannot hide here)
 FLIP_RATE = 2e-6     # share of an activation's elements that may differ (observed: 3-13 of 3e7 decisions in the whole

@@ -12,7 +12,7 @@ if [ "$mode" = build ]; then
   make -s -C $CS
   mkdir -p tools/abl
   for n in "$@"; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -DHCONV_ABL=$n \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -DHCONV_ABL=$n \
       -c $CS/sr3d_hconv.hip -o tools/abl/hconv_abl$n.o
     objs=$(ls $CS/*.o | grep -v sr3d_hconv.o)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/abl/libsr3d_habl$n.so $objs tools/abl/hconv_abl$n.o
