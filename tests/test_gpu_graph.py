@@ -204,7 +204,7 @@ def test_lazy_graphed_step_falls_back_to_eager_when_the_capture_fails(eng, monke
     eager = [_eager(m1, lf1, o1, *bt) for bt in batches]
 
     class Boom(graph_mod.GraphedTrainStep):
-        def __init__(self, model, loss_fn, optimizer, Xs, bs, ys, warmup=2):
+        def __init__(self, model, loss_fn, optimizer, Xs, bs, ys, warmup=2, **kwargs):
             for _ in range(2):          # a warm-up that moves the optimizer state, then a failing capture
                 loss = loss_fn(model(Xs, bs), ys, bs)
                 optimizer.zero_grad()
@@ -219,3 +219,18 @@ def test_lazy_graphed_step_falls_back_to_eager_when_the_capture_fails(eng, monke
     assert gs.failed and gs.graphed is None
     assert got == eager                                         # state restored, then plain eager steps
     assert torch.equal(o1.flat_param, o2.flat_param)
+
+    # ... but only a capture invalidation is downgraded to eager steps: an engine error, an out-of-memory condition or a
+    # sticky HIP error must surface (and the optimizer state is still put back)
+    class Broken(graph_mod.GraphedTrainStep):
+        def __init__(self, model, loss_fn, optimizer, Xs, bs, ys, warmup=2, **kwargs):
+            optimizer.flat_param.add_(1.0)
+            raise RuntimeError("sr3d_conv3d_fwd: invalid argument")
+
+    monkeypatch.setattr(graph_mod, "GraphedTrainStep", Broken)
+    m3, lf3, o3 = _setup(eng, cfg, sd, capturable=True)
+    before = o3.flat_param.clone()
+    gs3 = LazyGraphedStep(m3, lf3, o3)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        gs3(*batches[0])
+    assert not gs3.failed and torch.equal(o3.flat_param, before)
