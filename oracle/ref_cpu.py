@@ -30,6 +30,39 @@ StateDict = Dict[str, Tensor]
 
 
 # --------------------------------------------------------------------------
+# weight / bias gradient of a 3x3x3, pad-1, stride-1 convolution written out tap by tap
+# --------------------------------------------------------------------------
+def conv3d_weight_grad_by_taps(x: Tensor, dpre: Tensor, dtype=torch.float64) -> Tuple[Tensor, Tensor]:
+    """(dW, db) of ``pre = conv3d(x, W, b, stride=1, padding=1)`` given dL/dpre -- what autograd's
+    ``convolution_backward`` returns for the weight and bias of the reference's layers (nn.Conv3d at
+    pytorch/model/unet.py:100,196,240; custom_conv.py:289-294), restated as the 27 plain contractions
+
+        dW[n, c, kz, ky, kx] = sum_{b, z, y, x} dpre[b, n, z, y, x] * x[b, c, z + kz - 1, y + ky - 1, x + kx - 1]
+
+    (out-of-range x = 0), each ONE matrix product over the voxels, accumulated in ``dtype``.  Device-agnostic: the
+    full-size tests (tests/test_gpu_fullsize.py) evaluate it in fp64 on the tensors of a whole-model step where they
+    live (8 M voxels x 64..194 channels is minutes of CPU time and seconds on the GPU's fp64 GEMM); it is pinned to
+    autograd's result on the CPU by tests/test_oracle_golden.py."""
+    B, C, Z, Y, X = x.shape
+    N = dpre.shape[1]
+    assert dpre.shape[0] == B and tuple(dpre.shape[2:]) == (Z, Y, X)
+    dw = torch.zeros(N, C, 3, 3, 3, dtype=dtype, device=x.device)
+    for kz in range(3):
+        z0, z1 = max(0, 1 - kz), min(Z, Z + 1 - kz)          # output planes whose tap kz falls inside the input
+        for ky in range(3):
+            y0, y1 = max(0, 1 - ky), min(Y, Y + 1 - ky)
+            for kx in range(3):
+                x0, x1 = max(0, 1 - kx), min(X, X + 1 - kx)
+                for b in range(B):     # one matrix product per z plane (a batch): parallel work for any backend
+                    d = dpre[b, :, z0:z1, y0:y1, x0:x1].permute(1, 0, 2, 3).reshape(z1 - z0, N, -1).to(dtype)
+                    xs = x[b, :, z0 + kz - 1:z1 + kz - 1, y0 + ky - 1:y1 + ky - 1, x0 + kx - 1:x1 + kx - 1]
+                    xs = xs.permute(1, 0, 2, 3).reshape(z1 - z0, C, -1).to(dtype)
+                    dw[:, :, kz, ky, kx] += torch.bmm(d, xs.transpose(1, 2)).sum(0)
+    db = dpre.to(dtype).sum(dim=(0, 2, 3, 4))
+    return dw, db
+
+
+# --------------------------------------------------------------------------
 # index permutations  (pytorch/model/voxel_shuffle.py:5-42)
 # --------------------------------------------------------------------------
 def unshuffle_voxels(x: Tensor, factor: int = 2) -> Tensor:

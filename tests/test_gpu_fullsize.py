@@ -349,3 +349,207 @@ def test_training_step_is_bit_reproducible(eng):
         outs.append((float(loss), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] as a WHOLE: one training step of the default.yml model at HR 80x320x320, checked layer by layer
+# ------------------------------------------------------------------------------------------------------------------
+def _window_oracle(call, lo, hi):
+    """the oracle's output of one recorded layer on the output window [lo, hi), from a crop of the layer's REAL inputs"""
+    s = call["stride"]
+    grid = tuple(call["srcs"][0].shape[2:])
+    ilo = [max(0, l * s - 1) for l in lo]
+    ihi = [min(f, (h - 1) * s + 2) for h, f in zip(hi, grid)]
+    xc = torch.cat([_crop(t, ilo, ihi) for t in call["srcs"]], 1).float().cpu()
+    pad = []
+    for d in (2, 1, 0):
+        pad += [1 if lo[d] * s - 1 < 0 else 0, 1 if (hi[d] - 1) * s + 2 > grid[d] else 0]
+    xc = F.pad(xc, pad)
+    w = call["w"].detach().cpu()
+    bias = call["bias"].detach().cpu() if call["bias"] is not None else None
+    if call["kind"] == "gated":
+        feat = F.conv3d(xc, w, call["b_feat"].detach().cpu() if call["b_feat"] is not None else None, stride=s)
+        gate = torch.sigmoid(F.conv3d(xc, call["w_gate"].detach().cpu(), bias, stride=s))
+        return gate * (F.relu(feat) if call["act"] == "relu" else feat)
+    pre = F.conv3d(xc, w, bias, stride=s)
+    out = F.leaky_relu(pre, 0.01) if call["act"] == "lrelu" else pre
+    return R.unshuffle_voxels(out, 2) if call["unshuffle"] else out
+
+
+def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeypatch):
+    """One training step (forward, L1 loss, backward) of the default.yml model on BASELINE configs[1]'s volume -- LR 20x80x80
+    -> HR 80x320x320, the bench's own seeds and inputs, default dispatch -- with every convolution checked IN PLACE against
+    the oracle: the U-Net's receptive field (~170 voxels) rules out cropping the model, so each of its 34 layers is
+    compared on windows (corner, far corner, interior) with the oracle applied to crops of the inputs that layer really
+    received; for the layers that carry the step's time (`last`, up1.convs.1, up1.convs.0, up1.up.0) the input gradient is
+    checked the same way on windows, and the weight and bias gradients -- sums over all 8.2 M voxels -- against the
+    oracle's tap-by-tap contraction evaluated in fp64 (oracle/ref_cpu.py:conv3d_weight_grad_by_taps, pinned on the CPU).
+    reference: pytorch/model/unet.py:253-297, pytorch/src/optim_helper.py:160-165."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_config, synthetic_batch
+    cfg = make_config("l1")
+    torch.manual_seed(42)
+    model = eng.make_model(cfg).to(DEV)
+    names = {id(p): n for n, p in model.named_parameters()}
+    x, b, y = synthetic_batch(1, FULL, 4, 1234, DEV)
+    calls = []
+    orig_plain, orig_gated = eng.ops.conv3d_act, eng.ops.gated_conv3d_act
+
+    def rec_plain(srcs, weight, bias=None, act=None, stride=1, unshuffle=False):
+        out = orig_plain(srcs, weight, bias, act=act, stride=stride, unshuffle=unshuffle)
+        calls.append({"kind": "plain", "name": names[id(weight)].rsplit(".", 1)[0], "srcs": [t.detach() for t in srcs],
+                      "src_objs": list(srcs), "w": weight, "bias": bias, "act": act, "stride": stride, "unshuffle": unshuffle,
+                      "out": out})
+        return out
+
+    def rec_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):
+        out = orig_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=act, stride=stride)
+        calls.append({"kind": "gated", "name": names[id(w_feat)].rsplit(".", 1)[0], "srcs": [t.detach() for t in srcs],
+                      "w": w_feat, "w_gate": w_gate, "b_feat": b_feat, "bias": b_gate, "act": act, "stride": stride,
+                      "unshuffle": False, "out": out})
+        return out
+
+    monkeypatch.setattr(eng.ops, "conv3d_act", rec_plain)
+    monkeypatch.setattr(eng.ops, "gated_conv3d_act", rec_gated)
+    pred = model(x, b)
+    monkeypatch.undo()
+    assert len(calls) == 34 - 9           # 34 nn.Conv3d of the reference = 9 fused gated pairs + 16 plain layers
+    assert tuple(pred.shape) == (1, 4, *FULL)
+
+    # ---- forward: every layer on three windows of its own output grid
+    worst = ("", 0.0)
+    for c in calls:
+        og = tuple(c["out"].shape[2:])
+        f = 2 if c["unshuffle"] else 1                  # windows are chosen on the conv's (coarse) output grid
+        cg = tuple(v // f for v in og)
+        size = (3, 5, 36)
+        far = tuple(max(0, g - d) for g, d in zip(cg, size))
+        mid = tuple(max(0, min(g - d, g // 2 - d // 2 + o)) for g, d, o in zip(cg, size, (1, 1, -3)))
+        for lo in {(0, 0, 0), far, mid}:
+            hi = tuple(min(g, l + d) for g, l, d in zip(cg, lo, size))
+            ref = _window_oracle(c, lo, hi)
+            got = _crop(c["out"].detach(), [f * l for l in lo], [f * h for h in hi]).float().cpu()
+            e = relerr(got, ref)
+            worst = max(worst, (c["name"], e), key=lambda t: t[1])
+            assert e < TOL, (c["name"], lo, e)
+    print(f"forward, 25 fused layers x 3 windows at full size: worst {worst[0]} {worst[1]:.2e}")
+
+    # ---- loss and backward
+    by_name = {c["name"]: c for c in calls}
+    heavy = ["last", "up1.convs.1.conv", "up1.convs.0.conv", "up1.up.0"]
+    dys = {}
+    for n in heavy + ["up2.convs.1.conv"]:          # (the last one: its gradient is up1.up.0's input gradient)
+        by_name[n]["out"].register_hook(lambda g, n=n: dys.__setitem__(n, g.detach()))
+    loss = eng.make_loss(cfg)(pred, y, b)
+    ref_loss = (pred.detach().double() - y.double()).abs().mean()
+    assert abs(float(loss.detach()) - float(ref_loss)) <= TOL * float(ref_loss)
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert relerr(dys["last"], torch.sign(pred.detach() - y) / pred.numel()) < 1e-6       # dL/dpred of the L1 loss
+    for n in heavy:
+        c = by_name[n]
+        out, dy = c["out"].detach(), dys[n]
+        if c["act"] == "lrelu":
+            dpre = dy * torch.where(out > 0, 1.0, 0.01)
+            # (an element within rounding distance of the kink may fall on either side; none of these layers' outputs is
+            #  exactly 0 on this data, and the engine decides on the same stored y)
+        else:
+            dpre = dy
+        if c["unshuffle"]:
+            dpre = R.shuffle_voxels(dpre, 2)
+        xin = torch.cat(c["srcs"], 1)
+        dw_ref, db_ref = R.conv3d_weight_grad_by_taps(xin, dpre)
+        e_w = relerr(c["w"].grad, dw_ref)
+        print(f"{n}: weight gradient vs fp64 tap contraction over {xin[0, 0].numel()} voxels: {e_w:.2e}")
+        assert e_w < TOL, (n, e_w)
+        if c["bias"] is not None:
+            assert relerr(c["bias"].grad, db_ref) < TOL, n
+        del xin, dw_ref
+        # input gradient of the slices that carry one, on windows: conv_transpose of the (1-dilated) dpre crop
+        grid = tuple(c["srcs"][0].shape[2:])
+        w_cpu = c["w"].detach().cpu()
+        c0 = 0
+        for src, obj in zip(c["srcs"], c["src_objs"]):
+            ch = src.shape[1]
+            prod = next((k for k in calls if k["out"] is obj), None)
+            if prod is not None and prod["name"] in dys and obj.requires_grad:
+                got_full = dys[prod["name"]]            # the gradient that reached the producer = this layer's dx
+                for lo in [(0, 0, 0), tuple(g - d for g, d in zip(grid, (3, 5, 36))), (grid[0] // 2, grid[1] // 2 + 1, grid[2] // 2 - 9)]:
+                    hi = tuple(min(g, l + d) for g, l, d in zip(grid, lo, (3, 5, 36)))
+                    dlo, dhi = [max(0, l - 1) for l in lo], [min(g, h + 1) for h, g in zip(hi, grid)]
+                    dcrop = _crop(dpre, dlo, dhi).float().cpu()
+                    full = F.conv_transpose3d(dcrop, w_cpu[:, c0:c0 + ch], None, padding=1)     # grid [dlo, dhi)
+                    ref = _crop(full, [l - d for l, d in zip(lo, dlo)], [h - d for h, d in zip(hi, dlo)])
+                    e = relerr(_crop(got_full, lo, hi).float().cpu(), ref)
+                    assert e < TOL, (n, "dx", prod["name"], lo, e)
+            c0 += ch
+        del dpre
+
+
+def test_bf16_unshuffle_layer_at_configs4_size_beyond_2_32_elements_per_sample(eng):
+    """BASELINE configs[4]'s heaviest layer at ITS size: up1.up.0, 129 -> 1032 + bias + LeakyReLU + voxel unshuffle, bf16
+    storage, ONE sample on the 80x320x320 coarse grid -> (1, 129, 160, 640, 640) = 8.45e9 elements (17 GB): per-sample
+    element offsets beyond 2^32.  Operands are bf16-representable, so products are exact and the fp64 oracle on crops
+    is the arbiter (tests/test_gpu_bf16.py): forward windows at both ends of the tensor and in the interior; with dy
+    supported in a far window, the input gradient (zero elsewhere), the weight and the bias gradient."""
+    BF = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(404)
+    ca = 128
+    cgrid = (80, 320, 320)
+    xa = (torch.rand(1, ca, *cgrid, generator=g, device=DEV) - 0.3).to(BF).requires_grad_(True)
+    xb = (torch.rand(1, 1, *cgrid, generator=g, device=DEV) > 0.2).to(BF)
+    w = (torch.randn(8 * (ca + 1), ca + 1, 3, 3, 3, generator=g, device=DEV) * 0.03).to(BF).float().requires_grad_(True)
+    bias = (torch.randn(8 * (ca + 1), generator=g, device=DEV) * 0.1).requires_grad_(True)
+    y = eng.ops.conv3d_act([xa, xb], w, bias, act="lrelu", unshuffle=True)
+    assert y.dtype == BF and tuple(y.shape) == (1, ca + 1, 160, 640, 640) and y[0].numel() > 2 ** 32
+    w64, b64 = w.detach().double().cpu(), bias.detach().double().cpu()
+
+    def q(t):
+        return t.float().to(BF).double()
+
+    def one_ulp(got, ref, what):
+        got = got.float().cpu().double()
+        tol = 2.0 ** -7 * ref.abs() + 1e-5 * float(ref.pow(2).mean().sqrt())
+        bad = int(((got - ref).abs() > tol).sum())
+        assert bad == 0, (what, bad)
+
+    far_lo = (76, 313, 284)
+    windows = [((0, 0, 0), (3, 5, 36)), (far_lo, cgrid), ((41, 158, 150), (44, 163, 186))]
+    for lo, hi in windows:
+        i0 = [max(0, l - 1) for l in lo]
+        i1 = [min(f, h + 1) for h, f in zip(hi, cgrid)]
+        xc = torch.cat([_crop(xa.detach(), i0, i1), _crop(xb, i0, i1)], 1).double().cpu()
+        pad = []
+        for dd in (2, 1, 0):
+            pad += [1 if lo[dd] - 1 < 0 else 0, 1 if hi[dd] + 1 > cgrid[dd] else 0]
+        ref = q(R.unshuffle_voxels(F.leaky_relu(F.conv3d(F.pad(xc, pad), w64, b64), 0.01), 2))
+        one_ulp(_crop(y.detach(), [2 * l for l in lo], [2 * h for h in hi]), ref, ("y", lo))
+
+    # backward: dy supported in the FAR window (the last voxels of the 17 GB tensor), bf16-representable, off the kink
+    lo, hi = far_lo, cgrid
+    ilo, ihi = [l - 1 for l in lo], list(cgrid)
+    xc = torch.cat([_crop(xa.detach(), ilo, ihi), _crop(xb, ilo, ihi)], 1).double().cpu()
+    xcr, wr, br = xc.clone().requires_grad_(True), w64.clone().requires_grad_(True), b64.clone().requires_grad_(True)
+    pre = F.conv3d(F.pad(xcr, [0, 1, 0, 1, 0, 1]), wr, br)
+    gen = torch.Generator().manual_seed(9)
+    off_kink = R.unshuffle_voxels((pre.detach().abs() > 1e-2).double(), 2)
+    dyc = (torch.rand(off_kink.shape, generator=gen) - 0.5).to(BF).double() * off_kink
+    # the engine stores dpre = dy * act'(y) as bf16 (the slope is the fp32 constant 0.01f): the oracle rounds the same way
+    slope = torch.tensor(0.01, dtype=torch.float32).double()
+    dpre_ref = q(R.shuffle_voxels(dyc, 2) * torch.where(pre.detach() > 0, torch.ones((), dtype=torch.float64), slope))
+    pre.backward(dpre_ref)
+    dy = torch.zeros_like(y)
+    dy[:, :, 2 * lo[0]:, 2 * lo[1]:, 2 * lo[2]:] = dyc.to(DEV).to(BF)
+    y.backward(dy)
+    del dy, y
+    dx = xa.grad
+    outside = dx.clone()
+    outside[:, :, ilo[0]:, ilo[1]:, ilo[2]:] = 0
+    assert float(outside.float().abs().max()) == 0.0
+    del outside
+    one_ulp(_crop(dx, ilo, ihi), q(xcr.grad[:, :ca]), "dx")
+    assert relerr(w.grad, wr.grad) < TOL, relerr(w.grad, wr.grad)
+    assert relerr(bias.grad, br.grad) < TOL
