@@ -140,11 +140,18 @@ __device__ __forceinline__ void hconv_wait_vm(const int n) {
 // channels = four 16-byte pieces per part, no cross-lane exchange.  The timing-only build of the split form without the
 // raw-row loads (everything else kept) ran 20 % shorter, and more prefetch distance did not help: the loads cost
 // instruction slots of the texture path, not latency (profiles/r03e_ablation_hconv_kernel_fp32.log).
-template <int RT, bool BF, bool PAIR>
+// WIDE = 2 (bf16, X % 4 == 0, 8-byte aligned tensors; round 4): 8-byte QUADS of x-neighbours, 16 instead of 32 loads per lane and
+// chunk with the task geometry of the fp32 quads: a lane holds 4 voxels of its 8 channels as 8 x 2 dwords and builds the four
+// 16-byte pieces (voxel, 8 channels) with the same 32 v_perm per chunk as the pair form -- the refill costs vector-memory
+// INSTRUCTIONS (the timing-only build without it ran 37 % shorter), so half of them is the lever.
+template <int RT, bool BF, int WIDE>
 __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_kernel(const SrHconvParams p) {
   using G = HGeo<RT, BF>;
-  constexpr bool BPAIR = BF && PAIR, QUAD = !BF && PAIR;
-  constexpr int NR = BPAIR ? 4 : QUAD ? 2 : HNR;   // staging rounds
+  constexpr bool PAIR = WIDE != 0;
+  constexpr bool BQUAD = BF && WIDE == 2;
+  constexpr bool BPAIR = BF && WIDE == 1, QUAD = !BF && PAIR;
+  static_assert(BF || WIDE <= 1, "fp32: WIDE = 1 are the 16-byte quads");
+  constexpr int NR = BPAIR ? 4 : (QUAD || BQUAD) ? 2 : HNR;   // staging rounds
   constexpr int RV = QUAD ? 4 : 1;             // voxels per lane and round and channel in `raw`
   constexpr int HPX = 18;                      // bf16 pairs per halo row, covering hx = -1 .. 34
   constexpr int HQX = 10;                      // fp32 quads per halo row, covering hx = -3 .. 36
@@ -189,13 +196,13 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const int e = (r * 2 + (wave >> 1)) * 64 + lane;
-    if constexpr (QUAD) {   // quad q of row (hz, hy): x = x0 - 4 + 4 q .. + 3  <->  halo columns hx = 4 q - 3 .. 4 q
+    if constexpr (QUAD || BQUAD) {   // quad q of row (hz, hy): x = x0 - 4 + 4 q .. + 3  <->  halo columns hx = 4 q - 3 .. 4 q
       const int row = e / HQX, q = e - row * HQX;
       const int hz = row / HHY, hy = row - hz * HHY;
       const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 4 + 4 * q;
       const bool inrow = e < HHZ * HHY * HQX;
       const bool ok = inrow && (unsigned)gz < (unsigned)p.Z && (unsigned)gy < (unsigned)p.Y && (unsigned)gx < (unsigned)p.X;   // X % 4 == 0: all four or none
-      soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * 4u : 0xffffffffu;
+      soff[r] = ok ? (unsigned)((gz * p.Y + gy) * p.X + gx) * (unsigned)ESZ : 0xffffffffu;
       swr[r] = ((hz * HHY + hy) * HHX + 4 * q - 3) * 16;   // (of the quad's first voxel; may lie outside the row)
       swr2[r] = !inrow ? 0 : q == 0 ? 8 : q == HQX - 1 ? 1 : 15;
     } else if constexpr (BPAIR) {   // pair pp of row (hz, hy): x = x0 - 2 + 2 pp, + 1  <->  halo columns hx = 2 pp - 1, 2 pp
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
     const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
     return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
   };
-  float raw[NR][8 * RV];   // [round][channel][voxel of the quad]
+  float raw[NR][BQUAD ? 16 : 8 * RV];   // [round][channel][voxel of the quad]; bf16 quads: [round][channel][pair of the quad]
   // QUAD: channel c of this wave's 8, both rounds (two 16-byte loads per lane)
   auto load_raw_q = [&](const int chunk, const int c) {
     if constexpr (QUAD) {
@@ -263,6 +270,25 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
     if constexpr (QUAD) {
 #pragma unroll
       for (int c = 0; c < 8; c++) load_raw_q(chunk, c);
+      return;
+    }
+    if constexpr (BQUAD) {   // 8 channels x NR rounds of 8-byte loads (4 bf16 x-neighbours)
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int gc = chunk * HKC + sh * 8 + c;   // wave-uniform
+        const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          if constexpr ((HCONV_ABL & 64) != 0) {
+            asm volatile("" : "=v"(raw[r][2 * c]), "=v"(raw[r][2 * c + 1]));
+            continue;
+          }
+          const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, soff[r], 0, 0);
+          raw[r][2 * c] = __builtin_bit_cast(float, (unsigned)t[0]);
+          raw[r][2 * c + 1] = __builtin_bit_cast(float, (unsigned)t[1]);
+        }
+      }
       return;
     }
     const int gc0 = chunk * HKC + sh * 8;      // wave-uniform
@@ -347,7 +373,8 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
     const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
     return s_c < s_run ? s_c : s_run;
   };
-  h8 chi[NR * RV], clo[NR * RV];   // halo pieces of the next chunk, split (bf16 PAIR: the two voxels of the pair; QUAD: [round][voxel])
+  constexpr int NPC = (QUAD || BQUAD) ? NR * 4 : NR;   // 16-byte pieces a lane builds per chunk and part
+  h8 chi[NPC], clo[BQUAD ? 1 : NPC];   // halo pieces of the next chunk, split (bf16 PAIR: the two voxels of the pair; QUAD / bf16 quads: [round][voxel])
   // QUAD: one voxel of one round: 8 channels scaled and split = 24 vector instructions, placed next to 24 MFMAs
   auto convert_sub = [&](const int r, const int v, const float in_mult) {
     if constexpr (QUAD) {
@@ -362,7 +389,7 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
   auto convert = [&](const float in_mult) {
     if constexpr ((HCONV_ABL & 128) != 0) {
 #pragma unroll
-      for (int r = 0; r < NR; r++) asm volatile("" : "=v"(chi[r]), "=v"(clo[r]));
+      for (int r = 0; r < (BQUAD ? NPC : NR); r++) asm volatile("" : "=v"(chi[r]), "=v"(clo[BQUAD ? 0 : r]));
       return;
     }
 #pragma unroll
@@ -374,6 +401,22 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
           asm volatile("" : "+v"(chi[r * 4 + v]), "+v"(clo[r * 4 + v]));
           __builtin_amdgcn_sched_barrier(0);
         }
+        continue;
+      }
+      if constexpr (BQUAD) {   // dwords (2c, 2c + 1) = voxels (0, 1), (2, 3) of channel c  ->  four 16-byte pieces of 8 channels
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          u32x4 pc;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const unsigned a = __builtin_bit_cast(unsigned, raw[r][2 * (2 * k) + (v >> 1)]);
+            const unsigned bq = __builtin_bit_cast(unsigned, raw[r][2 * (2 * k + 1) + (v >> 1)]);
+            pc[k] = __builtin_amdgcn_perm(bq, a, (v & 1) ? 0x07060302u : 0x05040100u);   // channels 2k, 2k + 1 at voxel v
+          }
+          chi[r * 4 + v] = __builtin_bit_cast(h8, pc);
+          asm volatile("" : "+v"(chi[r * 4 + v]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
         continue;
       }
       if constexpr (BPAIR) {   // dword c = (voxel 0, voxel 1) of channel c  ->  two 16-byte pieces of 8 channels
@@ -416,6 +459,12 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
             *reinterpret_cast<h8*>(Hw + (0 * 2 + sh) * HPLANE + swr[r] + v * 16) = chi[r * 4 + v];
             *reinterpret_cast<h8*>(Hw + (1 * 2 + sh) * HPLANE + swr[r] + v * 16) = clo[r * 4 + v];
           }
+        continue;
+      }
+      if constexpr (BQUAD) {
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          if ((swr2[r] >> v) & 1) *reinterpret_cast<h8*>(Hw + sh * HPLANE + swr[r] + v * 16) = chi[r * 4 + v];
         continue;
       }
       if constexpr (BPAIR) {
@@ -965,7 +1014,7 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
 
 namespace {
 
-template <bool BF, bool PAIR>
+template <bool BF, int PAIR>
 int hconv_launch_t(SrHconvParams& p, int B, int n2, int n1, long long nsp, hipStream_t st) {
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
@@ -1016,9 +1065,15 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
   SR3D_CHECK(nsp * (n2 + n1) < (1ll << 31), SR3D_E_ARG, "split-f16 conv: grid too large");
   // wide halo loads: fp32 quads need X % 4 == 0 and 16-byte aligned tensors (then every channel row is), bf16 pairs even
   // rows and 4-byte aligned tensors
+  // (bf16: 8-byte quads where X % 4 == 0 and the tensors are 8-byte aligned, else 4-byte pairs; SR3D_HCONV_BF16_WIDE=1 keeps the pairs)
   const int wide = bf ? 2 : 4;
   bool pair = p.X % wide == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
-  for (int i = 0; i < p.in.n; i++) pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 3 : 15)) == 0;
-  if (!bf) return pair ? hconv_launch_t<false, true>(p, B, n2, n1, nsp, st) : hconv_launch_t<false, false>(p, B, n2, n1, nsp, st);
-  return pair ? hconv_launch_t<true, true>(p, B, n2, n1, nsp, st) : hconv_launch_t<true, false>(p, B, n2, n1, nsp, st);
+  bool bquad = bf && p.X % 4 == 0 && !(getenv("SR3D_HCONV_BF16_WIDE") && atoi(getenv("SR3D_HCONV_BF16_WIDE")) == 1);
+  for (int i = 0; i < p.in.n; i++) {
+    pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 3 : 15)) == 0;
+    bquad = bquad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 7) == 0;
+  }
+  if (!bf) return pair ? hconv_launch_t<false, 1>(p, B, n2, n1, nsp, st) : hconv_launch_t<false, 0>(p, B, n2, n1, nsp, st);
+  if (pair && bquad) return hconv_launch_t<true, 2>(p, B, n2, n1, nsp, st);
+  return pair ? hconv_launch_t<true, 1>(p, B, n2, n1, nsp, st) : hconv_launch_t<true, 0>(p, B, n2, n1, nsp, st);
 }
