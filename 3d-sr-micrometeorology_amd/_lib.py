@@ -50,6 +50,8 @@ SYMBOLS = {
     "sr3d_gated_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "sr3d_conv3d_bwd_data_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_data": (_I, [_DESC, _SL, _I, _P, _P, _SL, _I, _P, _SZ, _P]),
+    "sr3d_conv3d_bwd_data_fuses_act": (_I, [_DESC, _I, _SL, _I, _I]),
+    "sr3d_conv3d_bwd_data_act": (_I, [_DESC, _SL, _I, _P, _P, _SL, _I, _I, _P, _I, _P, _P, _SZ, _P]),
     "sr3d_conv3d_bwd_weight_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P, _P, _P]),
     "sr3d_bias_grad_workspace_bytes": (_SZ, [_I, _I, _LL]),

@@ -100,6 +100,12 @@ struct SrHconvParams {
   int TZ_, TY_, TX_;
   int unsh_C, Cg;
   unsigned* amax_out;  // optional [SR3D_MAX_SRC][64]: max |x| per K-side slice, a by-product of the block scaling (fp32 only)
+  // plain epilogue, input gradient: destination slice `act_slice1 - 1` (index into `out`) is the output y of a LeakyReLU layer;
+  // what is stored there is result * lrelu'(y) = that layer's dL/dpre (sr3d_conv3d_bwd_data_act), and max |stored| goes to
+  // act_amax[64] (optional, fp32: the scale of that layer's split-f16 weight gradient)
+  const void* act_y;
+  int act_slice1;      // 1 + slice index; 0 (a zero-initialised launch description): none
+  unsigned* act_amax;
 };
 int sr3d_hconv_mode();   // SR3D_SPLIT_F16: 0 off, 1 auto (default), 2 always
 // (bf: activations stored as bfloat16, one bf16 MFMA per product; sr3d_conv_desc_t.dtype == SR3D_DTYPE_BF16)

@@ -927,6 +927,25 @@ static int bwd_rows(const sr3d_slice_t* dx_dsts, int n_dst) {
     if (dx_dsts[i].ptr) n += dx_dsts[i].channels;
   return n;
 }
+// 1..4 gradient rows beyond a multiple of 64 that take the small-N VALU kernel instead of a padded MFMA tile (they are the
+// last channels of the last destination slice)
+static int bwd_rem_rows(const sr3d_conv_desc_t* d, int rows, int last_channels) {
+  const int rem = rows % 64;
+  if (!(rows > 64 && rem >= 1 && rem <= 4 && last_channels >= rem && (long long)d->Z * d->Y * d->X >= 500000) || is_bf(d)) return 0;
+  return rem;
+}
+// the fused activation epilogue exists in the split-f16 / bf16 stride-1 kernel only, and not for a slice whose last
+// channels leave for the VALU remainder kernel
+static bool bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice) {
+  if (check_desc(d) != SR3D_OK || d->stride != 1 || act_slice < 0 || act_slice >= n_dst || dx_dsts == nullptr) return false;
+  if (dx_dsts[act_slice].ptr == nullptr) return false;
+  const int rows = bwd_rows(dx_dsts, n_dst);
+  if (!use_hconv(d, n_dy * d->Cout, rows)) return false;
+  int last = -1;
+  for (int i = 0; i < n_dst; i++)
+    if (dx_dsts[i].ptr) last = i;
+  return !(last == act_slice && bwd_rem_rows(d, rows, dx_dsts[last].channels) > 0);
+}
 
 size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy) {
   if (check_desc(d) != SR3D_OK || (n_dy != 1 && n_dy != 2)) return 0;
@@ -943,9 +962,11 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
   return m > hs2 ? m : hs2;
 }
 
-int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+// the input gradient; act_slice >= 0: destination slice `act_slice` (index into dx_dsts) receives result * lrelu'(act_y)
+// (sr3d_conv3d_bwd_data_act) -- only the split-f16 / bf16 stride-1 kernel has that epilogue
+static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
                          const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         size_t workspace_bytes, void* stream, int act_slice, const void* act_y, void* act_absmax) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_feat && workspace && dx_dsts, SR3D_E_ARG, "conv3d_bwd_data: null pointer");
   SR3D_CHECK(n_dy == 1 || (n_dy == 2 && w_gate), SR3D_E_ARG, "conv3d_bwd_data: n_dy must be 1, or 2 with w_gate");
@@ -958,11 +979,12 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   // compacted destination list + row -> channel map
   sr3d_slice_t need[SR3D_MAX_SRC];
   PackParams pk{};
-  int nn = 0, ch = 0, rows = 0;
+  int nn = 0, ch = 0, rows = 0, act_nn = -1;
   for (int i = 0; i <= SR3D_MAX_SRC; i++) pk.rbeg[i] = INT_MAX;
   for (int i = 0; i < n_dst; i++) {
     SR3D_CHECK(dx_dsts[i].channels > 0, SR3D_E_ARG, "dx_dsts[%d]: channels must be positive", i);
     if (dx_dsts[i].ptr) {
+      if (i == act_slice) act_nn = nn;
       need[nn] = dx_dsts[i];
       pk.rbeg[nn] = rows, pk.cbeg[nn] = ch;
       rows += dx_dsts[i].channels;
@@ -992,13 +1014,14 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   float* image = (float*)workspace;
 
   const bool hconv = use_hconv(d, K, rows);
+  SR3D_CHECK(act_slice < 0 || (act_nn >= 0 && act_y != nullptr && bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice)), SR3D_E_ARG,
+             "conv3d_bwd_data_act: this launch has no fused activation epilogue (ask sr3d_conv3d_bwd_data_fuses_act first)");
   if (hconv || (use_wino(d) && K <= SR3D_WINO_MAX_K)) {
     // 1..4 gradient rows beyond a multiple of 64 (e.g. 193 = 3 * 64 + 1) would cost a whole 32-row Winograd tile per
     // voxel block: when they are the last channels of the last destination slice they take the small-N VALU kernel
-    int rem = rows % 64;
     const sr3d_slice_t& last = need[nn - 1];
     // (on the small grids of the deep levels the extra launches cost more than the padded tile)
-    if (!(rows > 64 && rem >= 1 && rem <= 4 && last.channels >= rem && (long long)d->Z * d->Y * d->X >= 500000) || is_bf(d)) rem = 0;
+    const int rem = bwd_rem_rows(d, rows, last.channels);
     const int main_rows = rows - rem;
     float* wsm = nullptr;   // image of the remainder rows
     if (hconv) {
@@ -1007,6 +1030,7 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
       q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
       q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
       q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
+      if (act_nn >= 0) q.act_slice1 = act_nn + 1, q.act_y = act_y, q.act_amax = is_bf(d) ? nullptr : (unsigned*)act_absmax;
       if (int rc = sr3d_hconv_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
       if (int rc = sr3d_hconv_launch(q, image, d->B, is_bf(d), st)) return rc;
       wsm = (float*)((unsigned char*)image + ((sr3d_hconv_image_bytes(main_rows, K, is_bf(d)) + 255) & ~(size_t)255));
@@ -1076,6 +1100,24 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   // grid of class 0 (even positions: the largest); ntaps of the launch-wide fields is only used for sizing
   p.OZ = p.cls[0].OZ, p.OY = p.cls[0].OY, p.OX = p.cls[0].OX, p.ntaps = 8;
   return launch<1, 0, 1, 2, 4>(p, d->B, rp, image, st);
+}
+
+int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+                         const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  return bwd_data_impl(d, dy_srcs, n_dy, w_feat, w_gate, dx_dsts, n_dst, workspace, workspace_bytes, stream, -1, nullptr, nullptr);
+}
+
+int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice) {
+  return bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice) ? 1 : 0;
+}
+
+int sr3d_conv3d_bwd_data_act(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+                             const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, const void* act_y,
+                             int act, void* act_absmax, void* workspace, size_t workspace_bytes, void* stream) {
+  SR3D_CHECK(act == SR3D_ACT_LRELU, SR3D_E_ARG, "conv3d_bwd_data_act: the fused epilogue is LeakyReLU'(y) (got act %d)", act);
+  SR3D_CHECK(act_slice >= 0 && act_slice < n_dst && act_y != nullptr, SR3D_E_ARG, "conv3d_bwd_data_act: bad act_slice / act_y");
+  return bwd_data_impl(d, dy_srcs, n_dy, w_feat, w_gate, dx_dsts, n_dst, workspace, workspace_bytes, stream, act_slice, act_y, act_absmax);
 }
 
 }  // extern "C"

@@ -88,10 +88,13 @@ class MyConvWithAct2(nn.Module):
         else:
             raise NotImplementedError(f"{conv_mode} is not supported.")
 
-    def forward(self, input: TensorOrList) -> torch.Tensor:
+    def forward(self, input: TensorOrList, defer_act_bwd: bool = False) -> torch.Tensor:
+        """``defer_act_bwd`` (engine extension, plain LeakyReLU layers): the caller guarantees that the output feeds exactly one
+        engine convolution, whose input-gradient kernel then applies this layer's activation backward (ops.Conv3dAct)"""
         srcs = _as_list(input)
         if self.conv_mode is None:
-            return ops.conv3d_act(srcs, self.conv.weight, self.conv.bias, act=self._act_name, stride=self.stride)
+            return ops.conv3d_act(srcs, self.conv.weight, self.conv.bias, act=self._act_name, stride=self.stride,
+                                  defer_act_bwd=defer_act_bwd)
         return self.conv.gated_forward(srcs, self._act_name)
 
 

@@ -52,11 +52,12 @@ class UpBlock(nn.Module):
         self.up = nn.Sequential(nn.Conv3d(in1_channels, in1_channels * 8, kernel_size=3, padding=1), nn.LeakyReLU(),
                                 VoxelUnshuffle(factor=2))
 
-    def forward(self, x1, x2) -> torch.Tensor:
+    def forward(self, x1, x2, defer_act_bwd: bool = False) -> torch.Tensor:
+        """``defer_act_bwd``: set by UNetSR, where every LeakyReLU output of this block feeds exactly one convolution"""
         x3 = ops.conv3d_act(_as_list(x1), self.up[0].weight, self.up[0].bias, act="lrelu", stride=1, unshuffle=True)
         y = _as_list(x2) + [x3]
         for layer in self.convs:
-            y = layer(y)
+            y = layer(y, defer_act_bwd=defer_act_bwd)
         return y
 
 
@@ -124,7 +125,7 @@ class UNetSR(nn.Module):
         y = srcs
         for layer in self.latent_layers:
             if isinstance(layer, nn.Conv3d):
-                y = ops.conv3d_act(_as_list(y), layer.weight, layer.bias, act="lrelu", stride=1)
+                y = ops.conv3d_act(_as_list(y), layer.weight, layer.bias, act="lrelu", stride=1, defer_act_bwd=True)
         return y
 
     def forward(self, x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -148,10 +149,12 @@ class UNetSR(nn.Module):
         else:
             f4 = self.down4([f3, b3])
             y = self._latent([f4, b4])
-            y = self.up4([y, b4], [f3, b3])
-        y = self.up3([y, b3], [f2, b2])
-        y = self.up2([y, b2], [f1, b1])
-        y = self.up1([y, b1], [f0, b])
+            y = self.up4([y, b4], [f3, b3], defer_act_bwd=True)
+        # (every LeakyReLU output below has ONE consumer, an engine convolution: its input-gradient epilogue applies the
+        #  activation backward -- SURVEY K9 -- where the kernel has that epilogue; ops.Conv3dAct falls back otherwise)
+        y = self.up3([y, b3], [f2, b2], defer_act_bwd=True)
+        y = self.up2([y, b2], [f1, b1], defer_act_bwd=True)
+        y = self.up1([y, b1], [f0, b], defer_act_bwd=True)
         w, bias = self.last.weight, self.last.bias
         pred = ops.conv3d_act([y, x0], w, bias, act=None, stride=1)
         return pred if self.act_dtype == torch.float32 else pred.float()

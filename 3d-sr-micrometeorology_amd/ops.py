@@ -41,11 +41,11 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
-def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of, x_amax=None, dy_amax=None):
+def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bias_of, x_amax=None, dy_amax=None, boxes=None):
     """(dxs, dw, [bias grads]) with the weight-side work on a side stream when the layer's grid is small"""
     vox = desc.Z * desc.Y * desc.X * desc.B
     if not want_w or not any(needs) or vox > CONCURRENT_WGRAD_MAX_VOXELS or L.PROFILING:
-        dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
+        dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate, boxes)
         dw = _bwd_weight(desc, srcs, dys, x_amax, dy_amax) if want_w else None
         return dxs, dw, [_bias_grad(t) if t is not None else None for t in bias_of]
     cur = torch.cuda.current_stream(dys[0].device)
@@ -54,7 +54,7 @@ def _grads_two_streams(desc, srcs, needs, dys, w_feat, w_gate, want_w: bool, bia
     with torch.cuda.stream(side):
         dw = _bwd_weight(desc, srcs, dys, x_amax, dy_amax)
         dbs = [_bias_grad(t) if t is not None else None for t in bias_of]
-    dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate)
+    dxs = _bwd_data(desc, srcs, needs, dys, w_feat, w_gate, boxes)
     cur.wait_stream(side)                      # join: everything returned is ready in current-stream order
     for t in [dw] + dbs:
         if t is not None:
@@ -128,7 +128,22 @@ def _bwd_weight(desc: L.ConvDesc, srcs, dys, x_amax=None, dy_amax=None) -> torch
     return dw
 
 
-def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate) -> List[Optional[torch.Tensor]]:
+# activation backward of LeakyReLU layers fused into their consumer's input-gradient epilogue where the model asks
+# for it (`defer_act_bwd`) and the kernel has the epilogue; False keeps the separate lrelu_bwd pass (tests: A/B, bit-equality)
+FUSE_ACT_BWD = os.environ.get("SR3D_FUSE_ACT_BWD", "1") != "0"
+
+
+class _ActBox:
+    """Shared by a LeakyReLU layer that deferred its activation backward (``defer_act_bwd=True``) and the convolution that
+    consumes its output: when the consumer's input-gradient kernel has the fused epilogue (sr3d_conv3d_bwd_data_act), what
+    it hands back through autograd is already dL/dpre of the producer (``done``), with max |dL/dpre| in ``amax``."""
+    __slots__ = ("done", "amax")
+
+    def __init__(self):
+        self.done, self.amax = False, None
+
+
+def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate, boxes=None) -> List[Optional[torch.Tensor]]:
     if not any(needs):
         return [None] * len(srcs)
     nbytes = L.lib.sr3d_conv3d_bwd_data_workspace_bytes(C.byref(desc), len(dys))
@@ -136,8 +151,20 @@ def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate
     outs: List[Optional[torch.Tensor]] = [torch.empty_like(s) if n else None for s, n in zip(srcs, needs)]
     dsts = [o if o is not None else (int(s.shape[1]), None) for o, s in zip(outs, srcs)]
     dt = L.torch_dtype(desc)
+    dst_arr = L.slices(dsts, "dx_dsts", dt)
+    # activation backward of a source layer fused into the epilogue (one slice at most: srcs[i] IS that layer's output y)
+    fuse = next((i for i, (bx, n) in enumerate(zip(boxes or [], needs)) if bx is not None and n), None) if FUSE_ACT_BWD else None
+    if fuse is not None and L.lib.sr3d_conv3d_bwd_data_fuses_act(C.byref(desc), len(dys), dst_arr, len(dsts), fuse):
+        box = boxes[fuse]
+        box.amax = _amax_slots(1, dys[0]) if dt == torch.float32 else None
+        L.check(L.lib.sr3d_conv3d_bwd_data_act(C.byref(desc), L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(w_feat),
+                                               L.dev_ptr(w_gate), dst_arr, len(dsts), fuse, L.dev_ptr(srcs[fuse], "act_y", dt),
+                                               L.ACT_CODE["lrelu"], _raw_ptr(box.amax), L.dev_ptr(ws), nbytes, L.stream_ptr()),
+                "sr3d_conv3d_bwd_data_act")
+        box.done = True
+        return outs
     L.check(L.lib.sr3d_conv3d_bwd_data(C.byref(desc), L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(w_feat),
-                                       L.dev_ptr(w_gate), L.slices(dsts, "dx_dsts", dt), len(dsts), L.dev_ptr(ws), nbytes,
+                                       L.dev_ptr(w_gate), dst_arr, len(dsts), L.dev_ptr(ws), nbytes,
                                        L.stream_ptr()), "sr3d_conv3d_bwd_data")
     return outs
 
@@ -150,7 +177,9 @@ class Conv3dAct(torch.autograd.Function):
     (latent), :240-246 (last); custom_conv.py:111-116."""
 
     @staticmethod
-    def forward(ctx, weight, bias, act: Optional[str], stride: int, unshuffle: bool, *srcs):
+    def forward(ctx, weight, bias, act: Optional[str], stride: int, unshuffle: bool, defer_act_bwd: bool, *srcs):
+        # sources that are outputs of LeakyReLU layers which deferred their activation backward to THIS layer's input gradient
+        ctx.src_boxes = [getattr(s, "_sr3d_act_box", None) for s in srcs]
         srcs = [s.contiguous() for s in srcs]
         B, cin, (Z, Y, X) = _check_srcs(srcs)
         cout = int(weight.shape[0])
@@ -177,6 +206,11 @@ class Conv3dAct(torch.autograd.Function):
             KINK_LOG.append((y > 0).cpu())
         ctx.desc, ctx.act, ctx.unshuffle, ctx.has_bias, ctx.nsrc = desc, act, unshuffle, bias is not None, len(srcs)
         ctx.save_for_backward(weight, y if act is not None else None, *srcs)
+        # `defer_act_bwd`: the caller guarantees that y feeds exactly ONE engine convolution; that layer's input
+        # gradient then stores dL/dy * lrelu'(y) directly and this layer's lrelu_bwd pass never runs (model/unet.py)
+        ctx.act_box = None
+        if defer_act_bwd and act == "lrelu" and not unshuffle and any(ctx.needs_input_grad):
+            ctx.act_box = y._sr3d_act_box = _ActBox()
         return y
 
     @staticmethod
@@ -187,7 +221,11 @@ class Conv3dAct(torch.autograd.Function):
         dy = dy.to(dt).contiguous()
         # max |dpre| for the weight gradient comes out of the activation-backward kernel (fp32 only)
         dy_amax = _amax_slots(1, dy) if (ctx.needs_input_grad[0] and dt == torch.float32 and ctx.act is not None) else None
-        if ctx.unshuffle:
+        box = ctx.act_box
+        if box is not None and box.done:      # the consumer's input-gradient epilogue already applied lrelu'(y)
+            dpre, dy_amax = dy, (box.amax if dy_amax is not None else None)
+            box.done, box.amax = False, None
+        elif ctx.unshuffle:
             B, c, z2, y2, x2 = dy.shape
             dpre = _empty((B, 8 * c, z2 // 2, y2 // 2, x2 // 2), dy, dt)
             if ctx.act != "lrelu":
@@ -203,11 +241,11 @@ class Conv3dAct(torch.autograd.Function):
             dpre = dy
         else:
             raise NotImplementedError(f"backward of plain conv with act={ctx.act}")
-        needs = ctx.needs_input_grad[5:5 + ctx.nsrc]
+        needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         dxs, dw, (db,) = _grads_two_streams(desc, srcs, needs, [dpre], weight, None, ctx.needs_input_grad[0],
-                                            [dpre if want_b else None], ctx.x_amax, dy_amax)
-        return (dw, db, None, None, None, *dxs)
+                                            [dpre if want_b else None], ctx.x_amax, dy_amax, ctx.src_boxes)
+        return (dw, db, None, None, None, None, *dxs)
 
 
 class GatedConv3dAct(torch.autograd.Function):
@@ -269,8 +307,8 @@ class GatedConv3dAct(torch.autograd.Function):
         return (dwf, dwg, dbf, dbg, None, None, *dxs)
 
 
-def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False):
-    return Conv3dAct.apply(weight, bias, act, stride, unshuffle, *srcs)
+def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False):
+    return Conv3dAct.apply(weight, bias, act, stride, unshuffle, defer_act_bwd, *srcs)
 
 
 def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):

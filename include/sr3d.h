@@ -125,6 +125,17 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
                          const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* The same with the activation backward of ONE destination slice fused into the epilogue: slice `act_slice` of
+ * cat(x) is the output y of a LeakyReLU layer (act = SR3D_ACT_LRELU; `act_y` = that tensor, same shape as the slice), and what
+ * is stored there is dL/dy * lrelu'(y) = dL/dpre of THAT layer -- its lrelu_bwd pass (autograd's leaky_relu_backward,
+ * pytorch/model/unet.py:72-97,192-199) never runs; in fp32 the stored values are bit-identical to sr3d_conv3d_bwd_data followed
+ * by sr3d_lrelu_bwd.  act_absmax (optional, [64] zeroed words, fp32 storage): max |stored| for that layer's weight gradient.
+ * Only launches for which sr3d_conv3d_bwd_data_fuses_act answers 1 have this epilogue (the split-f16 / bf16 stride-1 kernel). */
+int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice);
+int sr3d_conv3d_bwd_data_act(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
+                             const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, const void* act_y,
+                             int act, void* act_absmax, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[(n, c, kz,ky,kx)] over n in cat(dy_srcs) channels (so for gated layers dw = [dWf ; dWg]).
  * deterministic: fixed split of the voxel reduction + ordered second stage. */
 size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_total);

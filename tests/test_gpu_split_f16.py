@@ -308,3 +308,39 @@ def test_split_f16_stride2_weight_gradient_vs_fp64(eng, forced, cs, cout, grid, 
         wr = torch.zeros(cout, sum(cs), 3, 3, 3, dtype=torch.float64, requires_grad=True)
         F.conv3d(x64, wr, None, stride=2, padding=1).backward(d.double())
         assert relerr(outs[0][i * cout:(i + 1) * cout], wr.grad) < TOL, (i, relerr(outs[0][i * cout:(i + 1) * cout], wr.grad))
+
+
+def test_fused_activation_backward_equals_the_separate_pass_bit_for_bit(eng, monkeypatch):
+    """the LeakyReLU layers of the decoder defer their activation backward to the input-gradient epilogue of the
+    layer that consumes them (sr3d_conv3d_bwd_data_act, hconv_kernel's plain epilogue).  In fp32 the stored value is the very
+    expression of lrelu_bwd_kernel, and the maxima it exports are those of the same values: every parameter gradient of the
+    whole model must be BIT-identical with and without the fusion (split kernels forced so that the small grid takes them)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_config, synthetic_batch
+    monkeypatch.setenv("SR3D_SPLIT_F16", "2")
+    cfg = make_config("mixed")
+    x, b, y = synthetic_batch(1, (16, 32, 64), 4, 77, DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(eng.ops, "FUSE_ACT_BWD", fused)
+        torch.manual_seed(3)
+        model = eng.make_model(cfg).to(DEV)
+        calls = {"act": 0}
+        orig = eng._lib.lib.sr3d_lrelu_bwd
+
+        def counted(*a, _orig=orig):
+            calls["act"] += 1
+            return _orig(*a)
+        monkeypatch.setattr(eng._lib.lib, "sr3d_lrelu_bwd", counted)
+        loss = eng.make_loss(cfg)(model(x, b), y, b)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(eng._lib.lib, "sr3d_lrelu_bwd", orig)
+        res[fused] = ({k: p.grad.detach().clone() for k, p in model.named_parameters()}, calls["act"], float(loss.detach()))
+    assert res[True][2] == res[False][2]
+    # 11 plain LeakyReLU layers (3 latent + 8 UpBlock convs): all of them fused away, none on the reference path
+    assert res[False][1] == 11 and res[True][1] == 0, (res[True][1], res[False][1])
+    for k, g in res[True][0].items():
+        assert torch.equal(g, res[False][0][k]), k
