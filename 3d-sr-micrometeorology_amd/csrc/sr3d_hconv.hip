@@ -802,8 +802,41 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
     }
   } else {
     float amax_act = 0.f;   // largest |value| this thread stored into the activation-fused slice
+    // (voxel positions of this lane's four tiles, once)
+    long long spo[4];
+    bool sok[4];
 #pragma unroll
-    for (int i = 0; i < NRT; i++)
+    for (int j = 0; j < 4; j++) {
+      const int vt = 2 * wave + (j >> 1);
+      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
+      sok[j] = oz < p.Z && oy < p.Y && ox < p.X;
+      spo[j] = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+    }
+#pragma unroll
+    for (int i = 0; i < NRT; i++) {
+      // The slice that is the output y of a LeakyReLU layer: store result * lrelu'(y) -- that layer's dL/dpre -- instead of
+      // dL/dy, with y read at the element's own position (same shape as the destination).  The 16 y values of a row tile are
+      // fetched in ONE batch before its stores: a load behind every store (what the loop below would compile to: the
+      // destination and y may alias as far as the compiler knows) exposed a memory latency per element.
+      float yv[4][4];
+      bool fuse_r[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = rblock + i * 16 + rlane + r;
+        const int si = n < p.N ? cat_find(p.out, n) : -1;
+        fuse_r[r] = si >= 0 && si + 1 == p.act_slice1 && cat_ptr(p.out, si) != nullptr;
+        const long long boff = fuse_r[r] ? (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX : 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          yv[r][j] = 1.f;
+          if (fuse_r[r] && sok[j]) {
+            if constexpr (BF)
+              yv[r][j] = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p.act_y)[boff + spo[j]] << 16);
+            else
+              yv[r][j] = reinterpret_cast<const float*>(p.act_y)[boff + spo[j]];
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = rblock + i * 16 + rlane + r;
@@ -813,29 +846,19 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
         if (base == nullptr) continue;
         const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
         const float bv = p.bias ? p.bias[n] : 0.f;
-        // the slice that is the output y of a LeakyReLU layer: store result * lrelu'(y) -- that layer's dL/dpre -- instead of
-        // dL/dy, with y read at the element's own position (same shape as the destination)
-        const bool fuse = si + 1 == p.act_slice1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int vt = 2 * wave + (j >> 1);
-          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + (lane & 15);
-          if (oz < p.Z && oy < p.Y && ox < p.X) {
-            const long long o = boff + ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+          if (sok[j]) {
             float val = split_act(acc[i][j][r] * out_mult + bv, p.act);
-            if (fuse) {
-              float yv;
-              if constexpr (BF)
-                yv = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p.act_y)[o] << 16);
-              else
-                yv = reinterpret_cast<const float*>(p.act_y)[o];
-              val = yv > 0.f ? val : 0.01f * val;       // (the expression of lrelu_bwd_kernel: bit-identical in fp32)
+            if (fuse_r[r]) {
+              val = yv[r][j] > 0.f ? val : 0.01f * val;       // (the expression of lrelu_bwd_kernel: bit-identical in fp32)
               amax_act = fmaxf(amax_act, fabsf(val));
             }
-            st_act<BF>(base, o, val);
+            st_act<BF>(base, boff + spo[j], val);
           }
         }
       }
+    }
     if (!BF && p.act_amax != nullptr) {   // wave-uniform condition
       amax_act = split_wave_max(amax_act);
       if (lane == 0 && amax_act > 0.f) atomicMax(p.act_amax + (blockIdx.x & 63), __float_as_uint(amax_act));
