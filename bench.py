@@ -44,7 +44,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_
 F16_MFMA_SUSTAINED_TFLOPS = 1904.0
 # HBM traffic of the dominant kernel family per launch, from separate rocprofv3 --pmc passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass; FETCH_SIZE doubled as the guide prescribes for gfx950)
-TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json")]
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json")]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 BYTES_PER_VOXEL = 11_586       # compulsory fwd+bwd activation traffic per HR voxel, fp32
 FAMILIES = {"igemm_s1": 0, "igemm_s2": 1, "igemm_bwd_s2": 2, "wgrad": 3, "loss": 4, "act_bwd": 5, "bias_grad": 6,
