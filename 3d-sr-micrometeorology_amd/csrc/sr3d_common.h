@@ -103,6 +103,7 @@ struct SrHconvParams {
   // plain epilogue, input gradient: destination slice `act_slice1 - 1` (index into `out`) is the output y of a LeakyReLU layer;
   // what is stored there is result * lrelu'(y) = that layer's dL/dpre (sr3d_conv3d_bwd_data_act), and max |stored| goes to
   // act_amax[64] (optional, fp32: the scale of that layer's split-f16 weight gradient)
+  int out_f32;         // bf16 storage, plain epilogue: the destinations are fp32 tensors (the network's prediction: `last`)
   const void* act_y;
   int act_slice1;      // 1 + slice index; 0 (a zero-initialised launch description): none
   unsigned* act_amax;

@@ -854,7 +854,10 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
               val = yv[r][j] > 0.f ? val : 0.01f * val;       // (the expression of lrelu_bwd_kernel: bit-identical in fp32)
               amax_act = fmaxf(amax_act, fabsf(val));
             }
-            st_act<BF>(base, boff + spo[j], val);
+            if (BF && p.out_f32)
+              base[boff + spo[j]] = val;      // (fp32 destination of a bf16-storage layer)
+            else
+              st_act<BF>(base, boff + spo[j], val);
           }
         }
       }

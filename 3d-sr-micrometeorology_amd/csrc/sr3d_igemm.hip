@@ -805,7 +805,11 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
                     const void* bias, void* y, int act, int unshuffle, void* x_absmax, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "conv3d_fwd: null pointer");
+  const bool out_f32 = (act & SR3D_ACT_OUT_F32) != 0;
+  act &= ~SR3D_ACT_OUT_F32;
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "conv3d_fwd: unknown activation %d", act);
+  SR3D_CHECK(!out_f32 || (is_bf(d) && d->stride == 1 && !unshuffle), SR3D_E_ARG,
+             "conv3d_fwd: SR3D_ACT_OUT_F32 is the fp32 output of a bf16-storage, stride-1, plain layer");
   if (use_smalln_fwd(d, SR3D_PACK_FWD) && !unshuffle) {
     SmallFwdParams q{};
     if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &q.in, "x_srcs")) return rc;
@@ -826,6 +830,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     q.K = d->Cin, q.Z = d->Z, q.Y = d->Y, q.X = d->X, q.N = d->Cout;
     q.act = act, q.bias = (const float*)bias;
     q.amax_out = is_bf(d) ? nullptr : (unsigned*)x_absmax;
+    q.out_f32 = out_f32 ? 1 : 0;
     if (unshuffle) {
       SR3D_CHECK(d->Cout % 8 == 0 && bias != nullptr, SR3D_E_ARG,
                  "conv3d_fwd: unshuffle needs Cout %% 8 == 0 and a bias (Cout = %d)", d->Cout);

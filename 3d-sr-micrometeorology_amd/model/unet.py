@@ -156,5 +156,5 @@ class UNetSR(nn.Module):
         y = self.up2([y, b2], [f1, b1], defer_act_bwd=True)
         y = self.up1([y, b1], [f0, b], defer_act_bwd=True)
         w, bias = self.last.weight, self.last.bias
-        pred = ops.conv3d_act([y, x0], w, bias, act=None, stride=1)
-        return pred if self.act_dtype == torch.float32 else pred.float()
+        # (bf16 storage: the prediction leaves `last` as fp32, the accumulator's value -- not rounded to bf16 and cast back)
+        return ops.conv3d_act([y, x0], w, bias, act=None, stride=1, out_fp32=self.act_dtype != torch.float32)

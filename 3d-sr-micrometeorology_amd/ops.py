@@ -177,7 +177,7 @@ class Conv3dAct(torch.autograd.Function):
     (latent), :240-246 (last); custom_conv.py:111-116."""
 
     @staticmethod
-    def forward(ctx, weight, bias, act: Optional[str], stride: int, unshuffle: bool, defer_act_bwd: bool, *srcs):
+    def forward(ctx, weight, bias, act: Optional[str], stride: int, unshuffle: bool, defer_act_bwd: bool, out_fp32: bool, *srcs):
         # sources that are outputs of LeakyReLU layers which deferred their activation backward to THIS layer's input gradient
         ctx.src_boxes = [getattr(s, "_sr3d_act_box", None) for s in srcs]
         srcs = [s.contiguous() for s in srcs]
@@ -190,16 +190,21 @@ class Conv3dAct(torch.autograd.Function):
         desc = L.conv_desc(B, cin, cout, Z, Y, X, stride, dt)
         wp = pack_weights(desc, L.PACK_FWD_UNSHUFFLE if unshuffle else L.PACK_FWD, weight, None)
         oz, oy, ox = _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride)
+        # out_fp32 (bf16 storage only): the output leaves the engine as fp32 -- the network's prediction (model/unet.py)
+        out_fp32 = bool(out_fp32) and dt == torch.bfloat16
+        if out_fp32 and (unshuffle or stride != 1 or act is not None):
+            raise ValueError("out_fp32 is the un-rounded output of a plain stride-1 layer without activation (`last`)")
+        ydt = torch.float32 if out_fp32 else dt
         if unshuffle:
             y = _empty((B, cout // 8, 2 * oz, 2 * oy, 2 * ox), srcs[0], dt)
         else:
-            y = _empty((B, cout, oz, oy, ox), srcs[0], dt)
+            y = _empty((B, cout, oz, oy, ox), srcs[0], ydt)
         # max |x| per slice for the weight gradient, where the forward kernel has it as a by-product (fp32, split-f16 kernel)
         x_amax = None
         if ctx.needs_input_grad[0] and L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 0):
             x_amax = _amax_slots(4, srcs[0])
         L.check(L.lib.sr3d_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
-                                      L.dev_ptr(bias, "bias"), L.dev_ptr(y, "y", dt), L.ACT_CODE[act],
+                                      L.dev_ptr(bias, "bias"), L.dev_ptr(y, "y", ydt), L.ACT_CODE[act] | (L.ACT_OUT_F32 if out_fp32 else 0),
                                       int(bool(unshuffle)), _raw_ptr(x_amax), L.stream_ptr()), "sr3d_conv3d_fwd")
         ctx.x_amax = x_amax
         if KINK_LOG is not None and act is not None:
@@ -241,11 +246,11 @@ class Conv3dAct(torch.autograd.Function):
             dpre = dy
         else:
             raise NotImplementedError(f"backward of plain conv with act={ctx.act}")
-        needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
+        needs = ctx.needs_input_grad[7:7 + ctx.nsrc]
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         dxs, dw, (db,) = _grads_two_streams(desc, srcs, needs, [dpre], weight, None, ctx.needs_input_grad[0],
                                             [dpre if want_b else None], ctx.x_amax, dy_amax, ctx.src_boxes)
-        return (dw, db, None, None, None, None, *dxs)
+        return (dw, db, None, None, None, None, None, *dxs)
 
 
 class GatedConv3dAct(torch.autograd.Function):
@@ -307,8 +312,8 @@ class GatedConv3dAct(torch.autograd.Function):
         return (dwf, dwg, dbf, dbg, None, None, *dxs)
 
 
-def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False):
-    return Conv3dAct.apply(weight, bias, act, stride, unshuffle, defer_act_bwd, *srcs)
+def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False, out_fp32=False):
+    return Conv3dAct.apply(weight, bias, act, stride, unshuffle, defer_act_bwd, out_fp32, *srcs)
 
 
 def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):

@@ -145,6 +145,45 @@ class MixedGradientL2Loss(nn.Module):
         return mse if self._off() else mse + self.weight_gradient_loss * grd
 
 
+class MixedGradientWeightedL2Loss(nn.Module):
+    """loss_maker.py:304-355 (no ``make_loss`` branch selects it; constructor and methods as in the reference):
+    (w * mse_fluid + mse_buildings) / (w + 1) + w_g * grd_mse.  The first part is ``WeightedL2Loss`` (five sums of the fused
+    evaluation pass + one streaming gradient kernel), the gradient term the second entry of the fused mixed-loss kernel --
+    the reference's 4-channel mask sums to the same ``4 * sum(M) + 1`` denominator."""
+
+    def __init__(self, weight_outside_building: float, weight_gradient_loss: float):
+        super().__init__()
+        self.weight_outside_building = weight_outside_building
+        self.weight_gradient_loss = weight_gradient_loss
+
+    def _grd(self, predicts, targets, masks):
+        return ops.MixedLossFn.apply(predicts, targets, masks, [1.0, 1.0, 1.0], 5.0, 1.0, 0.0)[1]
+
+    def calc_loss_terms(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        """(one_region_diff, zero_region_diff, grd_mse), each differentiable"""
+        one = ops.WeightedLpFn.apply(predicts, targets, masks, 1.0e18, 2)       # w -> inf: the fluid voxels' average alone
+        zero = ops.WeightedLpFn.apply(predicts, targets, masks, 0.0, 2)          # w = 0: the buildings' average alone
+        return one, zero, self._grd(predicts, targets, masks)
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        mse = ops.WeightedLpFn.apply(predicts, targets, masks, float(self.weight_outside_building), 2)
+        return mse + self.weight_gradient_loss * self._grd(predicts, targets, masks)
+
+
+class ChannelwiseMse(nn.Module):
+    """loss_maker.py:753-764: mean squared error of ONE of the four channels (the mixed kernel's mse term on the slice)"""
+
+    def __init__(self, i_channel):
+        super().__init__()
+        self.i_channel = i_channel
+
+    def forward(self, predicts: torch.Tensor, targets: torch.Tensor, masks: torch.Tensor):
+        assert predicts.shape[1] == targets.shape[1] == 4
+        i = self.i_channel
+        d = predicts[:, i] - targets[:, i]      # (one channel of four: a strided slice; plain ATen on the device)
+        return (d * d).mean()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # evaluation metrics (no gradient): pytorch/src/loss_maker.py:453-745, used by script/train_model.py:366-390 and
 # the evaluation notebooks.  Constructor arguments and forward(predicts, targets, masks) as in the reference.

@@ -48,7 +48,8 @@ enum {
 enum { SR3D_DTYPE_F32 = 0, SR3D_DTYPE_BF16 = 1 };
 
 /* activations fused into conv epilogues (custom_conv.py:111-126, unet.py:35,84,105) */
-enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */ };
+enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */,
+       SR3D_ACT_OUT_F32 = 0x100 /* flag OR-ed to `act` of sr3d_conv3d_fwd: see there */ };
 
 /* One operand of a virtual channel concatenation (replaces torch.cat at
  * unet.py:255-293): `channels` channels of a (B, channels, Z, Y, X) tensor.
@@ -94,7 +95,9 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
 /* ---- forward ------------------------------------------------------------ */
 /* y = act(conv3d(cat(x_srcs); W) + bias)           nn.Conv3d + LeakyReLU: unet.py:196-198, 72-97, 240-246
  * unshuffle != 0: y is written as unshuffle_voxels(., 2) of that (voxel_shuffle.py:26-42, unet.py:99-108),
- *                 i.e. y has Cout/8 channels on the 2x grid. */
+ *                 i.e. y has Cout/8 channels on the 2x grid.
+ * act | SR3D_ACT_OUT_F32 (bf16 storage, stride 1, no unshuffle): y is an fp32 tensor -- the network's prediction (`last`,
+ *                 unet.py:240-246, 295) leaves the engine unrounded, the accumulator's value. */
 int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n_src, const void* w_packed,
                     const void* bias, void* y, int act, int unshuffle, void* x_absmax, void* stream);
 

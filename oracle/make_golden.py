@@ -377,6 +377,35 @@ def metrics_fixture():
 
 
 
+def extra_losses_fixture():
+    """the two loss classes no make_loss branch reaches (loss_maker.py:304-355 MixedGradientWeightedL2Loss, :753-764 ChannelwiseMse):
+    value, the three terms and dL/dp on the inputs of the metrics fixture"""
+    import src.loss_maker as LM
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_inputs
+    out = {}
+    for tag, (B, hr, seed, kind) in {"iid": (2, (8, 16, 24), 41, "iid"), "tower": (1, (16, 24, 40), 42, "tower")}.items():
+        _, b, y = synthetic_inputs(B, hr, 4, seed, kind)
+        g = torch.Generator().manual_seed(seed + 100)
+        p = y + 0.3 * (torch.rand(y.shape, generator=g) - 0.5)
+        out[f"{tag}/meta"] = np.array(json.dumps(dict(B=B, hr=hr, seed=seed, kind=kind)))
+        fn = LM.MixedGradientWeightedL2Loss(weight_outside_building=3.0, weight_gradient_loss=2.0)
+        pp = p.clone().requires_grad_(True)
+        v = fn(pp, y, b)
+        v.backward()
+        out[f"{tag}/MixedGradientWeightedL2"] = np.array(float(v), dtype=np.float64)
+        out[f"{tag}/MixedGradientWeightedL2/dp"] = npy(pp.grad)
+        out[f"{tag}/MixedGradientWeightedL2/terms"] = np.array([float(t) for t in fn.calc_loss_terms(p, y, b)], dtype=np.float64)
+        for i in range(4):
+            pp = p.clone().requires_grad_(True)
+            v = LM.ChannelwiseMse(i)(pp, y, b)
+            v.backward()
+            out[f"{tag}/ChannelwiseMse{i}"] = np.array(float(v), dtype=np.float64)
+            out[f"{tag}/ChannelwiseMse{i}/dp"] = npy(pp.grad)
+    np.savez_compressed(os.path.join(OUT, "losses_extra.npz"), **out)
+    print("losses_extra.npz", len(out))
+
+
 def pconv_fixture():
     """PartialConv3d (custom_conv.py:129-234): forward, updated mask and all gradients"""
     out = {}
@@ -483,6 +512,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pconv":
         pconv_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra_losses":
+        extra_losses_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         metrics_fixture()

@@ -600,6 +600,32 @@ def mixed_gradient_l2_loss(p: Tensor, t: Tensor, b: Tensor, w_g) -> Tensor:
     return mse if not w_g else mse + w_g * grd
 
 
+def mixed_gradient_weighted_l2_terms(p: Tensor, t: Tensor, b: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """``MixedGradientWeightedL2Loss.calc_loss_terms`` (loss_maker.py:313-343): squared error averaged over the fluid voxels
+    (mask 1) and over the buildings (mask 0), each with its ``+ 1`` in the denominator and the mask broadcast over the 4
+    channels, and the gradient term of the mixed losses (interior, off the walls; the 4-channel mask sums to 4 * sum(M))."""
+    d = p - t
+    sq = d ** 2
+    m = torch.broadcast_to(b, sq.shape)
+    one = (m * sq).sum() / (m.sum() + 1)
+    zero = ((1 - m) * sq).sum() / ((1 - m).sum() + 1)
+    near = near_wall_mask(b)
+    gm = (m * (1 - torch.broadcast_to(near, sq.shape)))[:, :, 1:-1, 1:-1, 1:-1]
+    g2 = sum(central_diff(d, ax, 1.0, padding=0) ** 2 for ax in ("x", "y", "z"))
+    return one, zero, (g2 * gm).sum() / (gm.sum() + 1)
+
+
+def mixed_gradient_weighted_l2_loss(p: Tensor, t: Tensor, b: Tensor, weight: float, w_g: float) -> Tensor:
+    """``MixedGradientWeightedL2Loss.forward`` (loss_maker.py:345-355)"""
+    one, zero, grd = mixed_gradient_weighted_l2_terms(p, t, b)
+    return (weight * one + zero) / (weight + 1) + w_g * grd
+
+
+def channelwise_mse(p: Tensor, t: Tensor, i_channel: int) -> Tensor:
+    """``ChannelwiseMse`` (loss_maker.py:753-764)"""
+    return ((p[:, i_channel] - t[:, i_channel]) ** 2).mean()
+
+
 def ssim3d(img1: Tensor, img2: Tensor, mask: Tensor, window_size: int = 11, sigma: float = 1.5, max_val: float = 1.0,
            eps: float = 1e-7, use_gaussian: bool = True, size_average: bool = True) -> Tensor:
     """``_ssim_3D`` (src/ssim.py:52-115) with its dense depthwise w x w x w window; mask already of img1's shape."""

@@ -112,6 +112,20 @@ def test_bf16_plain_conv_forward_and_input_gradient_exact(eng, cs, cout, grid, s
     assert relerr(dw, wr.grad) < 1e-5, relerr(dw, wr.grad)
 
 
+def test_bf16_last_layer_output_is_fp32_and_unrounded(eng):
+    """`last` in bf16 storage (unet.py:240-246, 295): bf16 inputs, the prediction written as fp32 straight from the
+    accumulator (SR3D_ACT_OUT_F32) -- 1e-5 against fp64 on bf16-representable operands, where a bf16-rounded output would
+    sit at 2^-9"""
+    xs, wf, _, bias = make_case([64, 5], 4, (4, 8, 40), seed=21)
+    ref = F.conv3d(torch.cat(xs, 1).double(), wf.double(), bias.double(), padding=1)
+    with torch.no_grad():
+        y = eng.ops.conv3d_act([x.to(DEV).to(BF) for x in xs], wf.to(DEV), bias.to(DEV), act=None, out_fp32=True)
+    assert y.dtype == torch.float32
+    assert relerr(y, ref) < 1e-5, relerr(y, ref)
+    with pytest.raises(ValueError):
+        eng.ops.conv3d_act([x.to(DEV).to(BF) for x in xs], wf.to(DEV), bias.to(DEV), act="lrelu", out_fp32=True)
+
+
 def test_bf16_unshuffle_epilogue_exact(eng):
     xs, wf, _, bias = make_case([33], 72, (5, 7, 33), seed=3)
     ref = q(R.unshuffle_voxels(F.leaky_relu(F.conv3d(xs[0].double(), wf.double(), bias.double(), padding=1), 0.01), 2))

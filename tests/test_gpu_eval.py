@@ -152,6 +152,35 @@ def test_other_make_loss_branches(eng, tag):
         assert relerr(q.grad, g[f"{tag}/{nm}/dp"]) < TOL, nm
 
 
+@pytest.mark.parametrize("tag", ["iid", "tower"])
+def test_unreached_loss_classes(eng, tag):
+    """MixedGradientWeightedL2Loss / ChannelwiseMse (loss_maker.py:304-355, 753-764): value, terms and dL/dp against the
+    reference's golden values"""
+    from sr3d_amd.src.loss_maker import ChannelwiseMse, MixedGradientWeightedL2Loss
+    g = load_golden("losses_extra.npz")
+    meta = json.loads(str(g[f"{tag}/meta"]))
+    _, b, y = synthetic_inputs(meta["B"], tuple(meta["hr"]), 4, meta["seed"], meta["kind"])
+    gen = torch.Generator().manual_seed(meta["seed"] + 100)
+    p = y + 0.3 * (torch.rand(y.shape, generator=gen) - 0.5)
+    fn = MixedGradientWeightedL2Loss(weight_outside_building=3.0, weight_gradient_loss=2.0)
+    q = p.to(DEV).requires_grad_(True)
+    v = fn(q, y.to(DEV), b.to(DEV))
+    v.backward()
+    ref = float(g[f"{tag}/MixedGradientWeightedL2"])
+    assert abs(float(v.detach()) - ref) <= TOL * abs(ref)
+    assert relerr(q.grad, g[f"{tag}/MixedGradientWeightedL2/dp"]) < TOL
+    with torch.no_grad():
+        for a, r in zip(fn.calc_loss_terms(p.to(DEV), y.to(DEV), b.to(DEV)), g[f"{tag}/MixedGradientWeightedL2/terms"]):
+            assert abs(float(a) - float(r)) <= TOL * abs(float(r)), (float(a), float(r))
+    for i in range(4):
+        q = p.to(DEV).requires_grad_(True)
+        v = ChannelwiseMse(i)(q, y.to(DEV), b.to(DEV))
+        v.backward()
+        ref = float(g[f"{tag}/ChannelwiseMse{i}"])
+        assert abs(float(v.detach()) - ref) <= TOL * abs(ref)
+        assert relerr(q.grad, g[f"{tag}/ChannelwiseMse{i}/dp"]) < TOL
+
+
 def test_ssim3d_vs_reference(eng):
     """SSIM3D / ssim3D / Ssim3dLoss (src/ssim.py, loss_maker.py:748-777) from the separable three-pass kernel"""
     from sr3d_amd.src.ssim import SSIM3D, ssim3D

@@ -397,8 +397,8 @@ def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeyp
     calls = []
     orig_plain, orig_gated = eng.ops.conv3d_act, eng.ops.gated_conv3d_act
 
-    def rec_plain(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False):
-        out = orig_plain(srcs, weight, bias, act=act, stride=stride, unshuffle=unshuffle, defer_act_bwd=defer_act_bwd)
+    def rec_plain(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False, out_fp32=False):
+        out = orig_plain(srcs, weight, bias, act=act, stride=stride, unshuffle=unshuffle, defer_act_bwd=defer_act_bwd, out_fp32=out_fp32)
         calls.append({"kind": "plain", "name": names[id(weight)].rsplit(".", 1)[0], "srcs": [t.detach() for t in srcs],
                       "src_objs": list(srcs), "w": weight, "bias": bias, "act": act, "stride": stride, "unshuffle": unshuffle,
                       "out": out, "deferred": getattr(out, "_sr3d_act_box", None) is not None})
