@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR3D_LIBRARY") or os.path.join(_HERE, "libsr3d.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_FROM_Y = 0x200    # flag OR-ed to `act` of sr3d_gated_act_bwd: its second operand is the layer output y
 ACT_OUT_F32 = 0x100   # flag OR-ed to `act` of sr3d_conv3d_fwd (include/sr3d.h): fp32 output of a bf16-storage layer
 DTYPE_F32, DTYPE_BF16 = 0, 1
 DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}

@@ -33,7 +33,9 @@ __device__ __forceinline__ void export_absmax(float m, unsigned* slots) {
 }
 
 // d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)        (T: storage type, float or bf16raw; fp32 arithmetic)
-template <typename T>
+// FROM_Y: the second operand is the layer's OUTPUT y = s * act(f) instead of act(f) (SR3D_ACT_FROM_Y): s > 0, so y has
+// the sign of act(f) -- the same act' -- and f * s = y: d_gate = dy * y * (1 - s).  The forward then stores no act(f) at all.
+template <typename T, bool FROM_Y>
 __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ f,
                                                                  const T* __restrict__ s, T* __restrict__ df,
                                                                  T* __restrict__ dg, long long n, int act, unsigned* amax) {
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __rest
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       o1[q] = a[q] * ss[q] * act_slope(ff[q], act);
-      o2[q] = a[q] * ff[q] * (ss[q] * (1.f - ss[q]));
+      o2[q] = FROM_Y ? a[q] * ff[q] * (1.f - ss[q]) : a[q] * ff[q] * (ss[q] * (1.f - ss[q]));
       m1 = fmaxf(m1, fabsf(o1[q])), m2 = fmaxf(m2, fabsf(o2[q]));
     }
     ActIo<T>::st4(df + 4 * i, o1);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __rest
   }
   for (long long i = n4 * 4 + i0; i < n; i += stride) {
     const float a = ActIo<T>::ld(dy + i), ff = ActIo<T>::ld(f + i), ss = ActIo<T>::ld(s + i);
-    const float v1 = a * ss * act_slope(ff, act), v2 = a * ff * (ss * (1.f - ss));
+    const float v1 = a * ss * act_slope(ff, act), v2 = FROM_Y ? a * ff * (1.f - ss) : a * ff * (ss * (1.f - ss));
     m1 = fmaxf(m1, fabsf(v1)), m2 = fmaxf(m2, fabsf(v2));
     ActIo<T>::st(df + i, v1);
     ActIo<T>::st(dg + i, v2);
@@ -412,6 +414,8 @@ int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, v
                        long long n, int act, int dtype, void* absmax_out, void* stream) {
   SR3D_DTYPE_CHECK(dtype, "gated_act_bwd");
   SR3D_CHECK(dy && save_f && save_s && d_feat && d_gate && n > 0, SR3D_E_ARG, "gated_act_bwd: bad argument");
+  const bool from_y = (act & SR3D_ACT_FROM_Y) != 0;
+  act &= ~SR3D_ACT_FROM_Y;
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_act_bwd: unknown activation %d", act);
   SR3D_ALIGN_CHECK(dy, "gated_act_bwd");
   SR3D_ALIGN_CHECK(save_f, "gated_act_bwd");
@@ -420,14 +424,21 @@ int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, v
   SR3D_ALIGN_CHECK(d_gate, "gated_act_bwd");
   const double esz = dtype == SR3D_DTYPE_BF16 ? 2.0 : 4.0;
   SrProfScope prof(SR3D_PROF_ACT_BWD, 5.0 * esz * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
-  if (dtype == SR3D_DTYPE_BF16)
-    hipLaunchKernelGGL(gated_act_bwd_kernel<bf16raw>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16raw*)dy, (const bf16raw*)save_f, (const bf16raw*)save_s, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act,
-                       (unsigned*)nullptr);
-  else
-    hipLaunchKernelGGL(gated_act_bwd_kernel<float>, dim3(blocks_for(n, 4)), dim3(kThreads), 0, (hipStream_t)stream,
-                     (const float*)dy, (const float*)save_f, (const float*)save_s, (float*)d_feat, (float*)d_gate, n,
-                     act, (unsigned*)absmax_out);
+  const dim3 grid(blocks_for(n, 4)), block(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SR3D_DTYPE_BF16) {
+    const bf16raw *a = (const bf16raw*)dy, *f = (const bf16raw*)save_f, *sg = (const bf16raw*)save_s;
+    if (from_y)
+      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, true>), grid, block, 0, st, a, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
+    else
+      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, false>), grid, block, 0, st, a, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
+  } else {
+    const float *a = (const float*)dy, *f = (const float*)save_f, *sg = (const float*)save_s;
+    if (from_y)
+      hipLaunchKernelGGL((gated_act_bwd_kernel<float, true>), grid, block, 0, st, a, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
+    else
+      hipLaunchKernelGGL((gated_act_bwd_kernel<float, false>), grid, block, 0, st, a, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
+  }
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

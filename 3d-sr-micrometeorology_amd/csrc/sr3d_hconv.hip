@@ -740,10 +740,8 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
               f = split_act(f, p.act);
               const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
               st_act<BF>(p.y, o, sg * f);
-              if (p.save_f) {
-                st_act<BF>(p.save_f, o, f);
-                st_act<BF>(p.save_s, o, sg);
-              }
+              if (p.save_f) st_act<BF>(p.save_f, o, f);
+              if (p.save_s) st_act<BF>(p.save_s, o, sg);
             }
           }
       }

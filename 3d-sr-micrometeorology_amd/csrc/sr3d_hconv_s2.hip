@@ -465,10 +465,8 @@ __global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hco
             f = split_act(f, p.act);
             const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
             st_act<BF>(p.y, o, s * f);
-            if (p.save_f) {
-              st_act<BF>(p.save_f, o, f);
-              st_act<BF>(p.save_s, o, s);
-            }
+            if (p.save_f) st_act<BF>(p.save_f, o, f);
+            if (p.save_s) st_act<BF>(p.save_s, o, s);
           }
         }
       }

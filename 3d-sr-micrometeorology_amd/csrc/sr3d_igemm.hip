@@ -237,10 +237,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
               f = act_apply(f, p.act);
               const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
               p.y[o] = s * f;
-              if (p.save_f) {
-                p.save_f[o] = f;
-                p.save_s[o] = s;
-              }
+              if (p.save_f) p.save_f[o] = f;
+              if (p.save_s) p.save_s[o] = s;
             }
           }
         }
@@ -888,7 +886,7 @@ int sr3d_gated_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs,
                           void* x_absmax, void* stream) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_packed && y, SR3D_E_ARG, "gated_conv3d_fwd: null pointer");
-  SR3D_CHECK((save_f == nullptr) == (save_s == nullptr), SR3D_E_ARG, "gated_conv3d_fwd: save_f/save_s go together");
+  SR3D_CHECK(save_f == nullptr || save_s != nullptr, SR3D_E_ARG, "gated_conv3d_fwd: save_f without save_s");
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_conv3d_fwd: unknown activation %d", act);
   if (use_hconv(d, d->Cin, hconv_fwd_rows(d, SR3D_PACK_FWD_GATED))) {
     SrHconvParams q{};

@@ -358,16 +358,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const SrWinoParams p) {
             float* o = eptr[rt][0] + (pl * pstride + yo * ystride);
             if (pair_ok && ox + 1 < p.X) {
               *reinterpret_cast<f32x2*>(o) = f32x2{sg[0] * f[0], sg[1] * f[1]};
-              if (p.save_f) {
-                *reinterpret_cast<f32x2*>(o + sf_off) = f32x2{f[0], f[1]};
-                *reinterpret_cast<f32x2*>(o + ss_off) = f32x2{sg[0], sg[1]};
-              }
+              if (p.save_f) *reinterpret_cast<f32x2*>(o + sf_off) = f32x2{f[0], f[1]};
+              if (p.save_s) *reinterpret_cast<f32x2*>(o + ss_off) = f32x2{sg[0], sg[1]};
             } else {
 #pragma unroll
               for (int xo = 0; xo < 2; xo++) {
                 if (ox + xo >= p.X) continue;
                 o[xo] = sg[xo] * f[xo];
-                if (p.save_f) o[sf_off + xo] = f[xo], o[ss_off + xo] = sg[xo];
+                if (p.save_f) o[sf_off + xo] = f[xo];
+                if (p.save_s) o[ss_off + xo] = sg[xo];
               }
             }
           }

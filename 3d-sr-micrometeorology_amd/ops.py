@@ -273,35 +273,37 @@ class GatedConv3dAct(torch.autograd.Function):
         oshape = (B, cout, _out_dim(Z, stride), _out_dim(Y, stride), _out_dim(X, stride))
         y = _empty(oshape, srcs[0], dt)
         need_bwd = any(ctx.needs_input_grad)
-        sf = _empty(oshape, y, dt) if need_bwd else None
+        # saved for backward: sigmoid(gate) and the output y itself (alive anyway as the next layer's input).  act(feat) is NOT
+        # stored: sigmoid > 0, so y has its sign (the same act') and act(feat) * sigmoid = y (sr3d_gated_act_bwd, SR3D_ACT_FROM_Y):
+        # one output-sized store in forward and one load in backward less per gated layer (6 GB per step at 80x320x320)
         ss = _empty(oshape, y, dt) if need_bwd else None
         x_amax = None
         if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and L.lib.sr3d_conv3d_fwd_exports_absmax(C.byref(desc), 1):
             x_amax = _amax_slots(4, srcs[0])
         L.check(L.lib.sr3d_gated_conv3d_fwd(C.byref(desc), L.slices(srcs, "x_srcs", dt), len(srcs), L.dev_ptr(wp),
                                             L.dev_ptr(b_feat, "feature bias"), L.dev_ptr(b_gate, "gate bias"),
-                                            L.dev_ptr(y, "y", dt), L.dev_ptr(sf, "save_f", dt),
+                                            L.dev_ptr(y, "y", dt), None,
                                             L.dev_ptr(ss, "save_s", dt), L.ACT_CODE[act], _raw_ptr(x_amax),
                                             L.stream_ptr()), "sr3d_gated_conv3d_fwd")
         ctx.x_amax = x_amax
         if KINK_LOG is not None and act is not None:
-            KINK_LOG.append((sf > 0).cpu())
+            KINK_LOG.append((y > 0).cpu())       # (the sign of act(feat): sigmoid > 0)
         ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
-        ctx.save_for_backward(w_feat, w_gate, sf, ss, *srcs)
+        ctx.save_for_backward(w_feat, w_gate, y if need_bwd else None, ss, *srcs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        w_feat, w_gate, sf, ss, *srcs = ctx.saved_tensors
+        w_feat, w_gate, y, ss, *srcs = ctx.saved_tensors
         desc = ctx.desc
         dt = L.torch_dtype(desc)
         dy = dy.to(dt).contiguous()
         d_feat, d_gate = torch.empty_like(dy), torch.empty_like(dy)
         want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dy_amax = _amax_slots(2, dy) if (want_w and dt == torch.float32) else None
-        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(sf, "save_f", dt), L.dev_ptr(ss, "save_s", dt),
+        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt), L.dev_ptr(ss, "save_s", dt),
                                          L.dev_ptr(d_feat, "d_feat", dt), L.dev_ptr(d_gate, "d_gate", dt), dy.numel(),
-                                         L.ACT_CODE[ctx.act], desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()),
+                                         L.ACT_CODE[ctx.act] | L.ACT_FROM_Y, desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()),
                 "sr3d_gated_act_bwd")
         needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
         dxs, dw, (dbf, dbg) = _grads_two_streams(

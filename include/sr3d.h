@@ -49,7 +49,8 @@ enum { SR3D_DTYPE_F32 = 0, SR3D_DTYPE_BF16 = 1 };
 
 /* activations fused into conv epilogues (custom_conv.py:111-126, unet.py:35,84,105) */
 enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */,
-       SR3D_ACT_OUT_F32 = 0x100 /* flag OR-ed to `act` of sr3d_conv3d_fwd: see there */ };
+       SR3D_ACT_OUT_F32 = 0x100 /* flag OR-ed to `act` of sr3d_conv3d_fwd: see there */,
+       SR3D_ACT_FROM_Y = 0x200 /* flag OR-ed to `act` of sr3d_gated_act_bwd: see there */ };
 
 /* One operand of a virtual channel concatenation (replaces torch.cat at
  * unet.py:255-293): `channels` channels of a (B, channels, Z, Y, X) tensor.
@@ -151,7 +152,9 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
 size_t sr3d_bias_grad_workspace_bytes(int B, int C, long long voxels);
 int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, void* workspace, int dtype, void* stream);
 
-/* d_feat = dy * s * act'(f),  d_gate = dy * f * s * (1 - s)      (autograd of custom_conv.py:119-123) */
+/* d_feat = dy * s * act'(f),  d_gate = dy * f * s * (1 - s)      (autograd of custom_conv.py:119-123); f = act(feat), s = sigmoid(gate)
+ * act | SR3D_ACT_FROM_Y: `save_f` is the layer's OUTPUT y = s * f instead (s > 0: y has the sign of f, and f * s = y), so the
+ * forward pass need not store act(feat) at all (sr3d_gated_conv3d_fwd with save_f = NULL, save_s given) */
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
                        long long n, int act, int dtype, void* absmax_out /* [2][64]: d_feat, d_gate */, void* stream);
 /* dpre = dy * (y > 0 ? 1 : 0.01)        (autograd of nn.LeakyReLU, y = post-activation) */

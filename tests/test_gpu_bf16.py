@@ -151,9 +151,10 @@ def test_bf16_gated_conv_forward_and_saved_tensors_exact(eng, cs, cout, grid, st
     g = torch.Generator().manual_seed(5)
     gy = rep(torch.rand(y.shape, generator=g) - 0.5)
     y.backward(gy.to(DEV).to(BF))
-    sf, ss = q(f), q(s)
-    d_feat = q(gy.double() * ss * (sf > 0))
-    d_gate = q(gy.double() * sf * (ss * (1.0 - ss)))
+    # the engine keeps sigmoid(g) and the output y (both bf16) for backward: y has the sign of act(f), and act(f) * sigmoid = y
+    yq, ss = y.detach().float().cpu().double(), q(s)     # (the stored output itself: one ulp around q(s * f), checked above)
+    d_feat = q(gy.double() * ss * (yq > 0))
+    d_gate = q(gy.double() * yq * (1.0 - ss))
     xr, wfr, wgr = x64.clone().requires_grad_(True), wf.double().requires_grad_(True), wg.double().requires_grad_(True)
     (F.conv3d(xr, wfr, None, stride=stride, padding=1) * d_feat).sum().backward()
     (F.conv3d(xr, wgr, None, stride=stride, padding=1) * d_gate).sum().backward()
