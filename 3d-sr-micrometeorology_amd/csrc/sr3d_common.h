@@ -103,6 +103,8 @@ struct SrHconvParams {
   // plain epilogue, input gradient: destination slice `act_slice1 - 1` (index into `out`) is the output y of a LeakyReLU layer;
   // what is stored there is result * lrelu'(y) = that layer's dL/dpre (sr3d_conv3d_bwd_data_act), and max |stored| goes to
   // act_amax[64] (optional, fp32: the scale of that layer's split-f16 weight gradient)
+  int vec_epi;         // set by sr3d_hconv_launch: X % 4 == 0 and every destination / y / save pointer 16-byte aligned -> the plain
+                       // and gated epilogues transpose their 16 x 16 tiles through LDS and store 4 x-neighbours at a time
   int out_f32;         // bf16 storage, plain epilogue: the destinations are fp32 tensors (the network's prediction: `last`)
   const void* act_y;
   int act_slice1;      // 1 + slice index; 0 (a zero-initialised launch description): none

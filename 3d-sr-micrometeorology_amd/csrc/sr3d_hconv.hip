@@ -719,6 +719,102 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
   const int rblock = p.n_off + (p.nb_off + nblk) * 64;        // first GEMM row of this workgroup
   const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
   const int rlane = 4 * (lane >> 4);
+  // ---- 16-byte epilogue (plain and gated, X % 4 == 0, aligned tensors).  A 16 x 16 accumulator tile has its 4 registers on 4
+  // ROWS: stored as it stands, every value is its own 4-byte access (64 stores per lane, + 64 loads with the fused activation
+  // backward), and the thin launches (conv0's forward, the input gradient of `last`, K = 4) are bound by exactly that number.
+  // Each wave transposes its tiles through its own 1.25 KB of the (now idle) LDS -- 4 ds_write_b32, 1 ds_read_b128, conflict-
+  // free with a pitch of 20 floats, no barrier: a wave's LDS operations execute in order -- and holds 4 x-NEIGHBOURS of one row.
+  if (p.vec_epi && (p.epi == SR3D_EPI_PLAIN || (p.epi == SR3D_EPI_GATED && RT == 2))) {
+    float* scr = reinterpret_cast<float*>(lds) + wave * 320;      // 16 rows x 20 floats
+    const int tr = lane >> 2, tc = 4 * (lane & 3);                // after the transpose: row of the tile, first of 4 columns
+    auto transpose = [&](const f32x4 a) -> f32x4 {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; r++) scr[(rlane + r) * 20 + (lane & 15)] = a[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const f32x4 t = *reinterpret_cast<const f32x4*>(scr + tr * 20 + tc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      return t;
+    };
+    auto store4 = [&](float* base, const long long o, const f32x4 v, const bool f32dst) {
+      if (BF && !f32dst) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
+        const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(base) + o) = u32x2{lo, hi};
+      } else {
+        *reinterpret_cast<f32x4*>(base + o) = v;
+      }
+    };
+    float amax_act = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int vt = 2 * wave + (j >> 1);
+      const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + tc;
+      const bool ok = oz < p.Z && oy < p.Y && ox < p.X;             // (X % 4 == 0: all four or none)
+      const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+      if (p.epi == SR3D_EPI_GATED) {
+        if constexpr (RT == 2) {
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const f32x4 fa = transpose(acc[i][j] * out_mult), ga = transpose(acc[2 + i][j] * out_mult);
+            const int co = rblock / 2 + i * 16 + tr;
+            if (ok && co < p.Cg) {
+              const float bf_ = p.bias ? p.bias[co] : 0.f, bg_ = p.bias2 ? p.bias2[co] : 0.f;
+              f32x4 yv, fv, sv;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float sg = 1.f / (1.f + expf(-(ga[e] + bg_)));
+                const float f = split_act(fa[e] + bf_, p.act);
+                yv[e] = sg * f, fv[e] = f, sv[e] = sg;
+              }
+              const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+              store4(p.y, o, yv, false);
+              if (p.save_f) store4(p.save_f, o, fv, false);
+              if (p.save_s) store4(p.save_s, o, sv, false);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NRT; i++) {
+          const f32x4 t = transpose(acc[i][j] * out_mult);
+          const int n = rblock + i * 16 + tr;
+          if (!ok || n >= p.N) continue;
+          const int si = cat_find(p.out, n);
+          float* base = cat_ptr(p.out, si);
+          if (base == nullptr) continue;
+          const long long o = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX + sp;
+          const float bv = p.bias ? p.bias[n] : 0.f;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = split_act(t[e] + bv, p.act);
+          if (si + 1 == p.act_slice1) {       // the fused activation backward of the producing layer (see the scalar form below)
+            f32x4 yv;
+            if constexpr (BF) {
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 yy = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.act_y) + o);
+              yv = f32x4{__builtin_bit_cast(float, yy[0] << 16), __builtin_bit_cast(float, yy[0] & 0xffff0000u),
+                         __builtin_bit_cast(float, yy[1] << 16), __builtin_bit_cast(float, yy[1] & 0xffff0000u)};
+            } else {
+              yv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.act_y) + o);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              v[e] = yv[e] > 0.f ? v[e] : 0.01f * v[e];
+              amax_act = fmaxf(amax_act, fabsf(v[e]));
+            }
+          }
+          store4(base, o, v, p.out_f32 != 0);
+        }
+      }
+    }
+    if (!BF && p.act_amax != nullptr) {
+      amax_act = split_wave_max(amax_act);
+      if (lane == 0 && amax_act > 0.f) atomicMax(p.act_amax + (blockIdx.x & 63), __float_as_uint(amax_act));
+    }
+    return;
+  }
   if (p.epi == SR3D_EPI_GATED) {
     if constexpr (RT == 2) {   // rows 0..31 of the block: features, 32..63: gates of the same 32 channels
 #pragma unroll
@@ -1116,6 +1212,19 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
   for (int i = 0; i < p.in.n; i++) {
     pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 3 : 15)) == 0;
     bquad = bquad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 7) == 0;
+  }
+  // the 16-byte epilogue: rows of 4 x-neighbours, every destination (and the tensors read or written next to it) aligned
+  {
+    const uintptr_t am = (bf && !p.out_f32) ? 7 : 15;
+    bool vec = p.X % 4 == 0 && p.TX_ == p.X && getenv("SR3D_HCONV_SCALAR_EPILOGUE") == nullptr && p.epi != SR3D_EPI_UNSHUFFLE;
+    if (p.epi == SR3D_EPI_GATED) {
+      vec = vec && (reinterpret_cast<uintptr_t>(p.y) & am) == 0 && (reinterpret_cast<uintptr_t>(p.save_f) & am) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.save_s) & am) == 0;
+    } else {
+      for (int i = 0; i < p.out.n; i++) vec = vec && (reinterpret_cast<uintptr_t>(p.out.ptr[i]) & am) == 0;
+      vec = vec && (reinterpret_cast<uintptr_t>(p.act_y) & (bf ? 7 : 15)) == 0;
+    }
+    p.vec_epi = vec ? 1 : 0;
   }
   if (!bf) return pair ? hconv_launch_t<false, 1>(p, B, n2, n1, nsp, st) : hconv_launch_t<false, 0>(p, B, n2, n1, nsp, st);
   if (pair && bquad) return hconv_launch_t<true, 2>(p, B, n2, n1, nsp, st);
