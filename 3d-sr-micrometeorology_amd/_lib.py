@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR3D_LIBRARY") or os.path.join(_HERE, "libsr3d.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_UNSHUFFLE = 0x400  # flag OR-ed to `act` of sr3d_conv3d_bwd_data_act: the fused slice is an unshuffle layer's output
 ACT_FROM_Y = 0x200    # flag OR-ed to `act` of sr3d_gated_act_bwd: its second operand is the layer output y
 ACT_OUT_F32 = 0x100   # flag OR-ed to `act` of sr3d_conv3d_fwd (include/sr3d.h): fp32 output of a bf16-storage layer
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -52,7 +53,7 @@ SYMBOLS = {
     "sr3d_gated_conv3d_fwd": (_I, [_DESC, _SL, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "sr3d_conv3d_bwd_data_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_data": (_I, [_DESC, _SL, _I, _P, _P, _SL, _I, _P, _SZ, _P]),
-    "sr3d_conv3d_bwd_data_fuses_act": (_I, [_DESC, _I, _SL, _I, _I]),
+    "sr3d_conv3d_bwd_data_fuses_act": (_I, [_DESC, _I, _SL, _I, _I, _I]),
     "sr3d_conv3d_bwd_data_act": (_I, [_DESC, _SL, _I, _P, _P, _SL, _I, _I, _P, _I, _P, _P, _SZ, _P]),
     "sr3d_conv3d_bwd_weight_workspace_bytes": (_SZ, [_DESC, _I]),
     "sr3d_conv3d_bwd_weight": (_I, [_DESC, _SL, _I, _SL, _I, _P, _P, _SZ, _P, _P, _P]),

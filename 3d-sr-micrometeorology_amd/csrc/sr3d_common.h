@@ -107,6 +107,7 @@ struct SrHconvParams {
                        // and gated epilogues transpose their 16 x 16 tiles through LDS and store 4 x-neighbours at a time
   int out_f32;         // bf16 storage, plain epilogue: the destinations are fp32 tensors (the network's prediction: `last`)
   const void* act_y;
+  int act_unsh;        // the fused slice is stored in the producer's SHUFFLED layout (8 C channels on the coarse grid); vec_epi only
   int act_slice1;      // 1 + slice index; 0 (a zero-initialised launch description): none
   unsigned* act_amax;
 };

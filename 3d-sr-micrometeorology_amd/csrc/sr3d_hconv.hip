@@ -746,6 +746,36 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
         *reinterpret_cast<f32x4*>(base + o) = v;
       }
     };
+    // The y values of the activation-fused slice, ALL of this wave's 16 tiles in one burst before anything is stored: fetched
+    // tile by tile behind the transposes, each load exposed a memory latency (16 per workgroup against the ~20 us a K = 64
+    // workgroup lives; hconv + 7 ms per step).  The accumulators are the only other live registers here.
+    f32x4 yfuse[4][NRT];
+    if (p.epi == SR3D_EPI_PLAIN && p.act_slice1 != 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int vt = 2 * wave + (j >> 1);
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3), ox = x0 + (j & 1) * 16 + tc;
+        const bool ok = oz < p.Z && oy < p.Y && ox < p.X;
+        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+#pragma unroll
+        for (int i = 0; i < NRT; i++) {
+          const int n = rblock + i * 16 + tr;
+          const int si = n < p.N ? cat_find(p.out, n) : -1;
+          yfuse[j][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+          if (ok && si >= 0 && si + 1 == p.act_slice1) {
+            const long long o = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX + sp;
+            if constexpr (BF) {
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 yy = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.act_y) + o);
+              yfuse[j][i] = f32x4{__builtin_bit_cast(float, yy[0] << 16), __builtin_bit_cast(float, yy[0] & 0xffff0000u),
+                                  __builtin_bit_cast(float, yy[1] << 16), __builtin_bit_cast(float, yy[1] & 0xffff0000u)};
+            } else {
+              yfuse[j][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.act_y) + o);
+            }
+          }
+        }
+      }
+    }
     float amax_act = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -790,19 +820,33 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = split_act(t[e] + bv, p.act);
           if (si + 1 == p.act_slice1) {       // the fused activation backward of the producing layer (see the scalar form below)
-            f32x4 yv;
-            if constexpr (BF) {
-              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-              const u32x2 yy = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.act_y) + o);
-              yv = f32x4{__builtin_bit_cast(float, yy[0] << 16), __builtin_bit_cast(float, yy[0] & 0xffff0000u),
-                         __builtin_bit_cast(float, yy[1] << 16), __builtin_bit_cast(float, yy[1] & 0xffff0000u)};
-            } else {
-              yv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.act_y) + o);
-            }
+            const f32x4 yv = yfuse[j][i];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               v[e] = yv[e] > 0.f ? v[e] : 0.01f * v[e];
               amax_act = fmaxf(amax_act, fabsf(v[e]));
+            }
+            if (p.act_unsh) {
+              // the producer is an unshuffle layer: its dL/dpre lives on the COARSE grid with 8 C channels, channel
+              // ((fz * 2 + fy) * 2 + fx) * C + c.  The lane's 4 fine x-neighbours are coarse x = ox / 2, ox / 2 + 1 of fx = 0
+              // (elements 0, 2) and of fx = 1 (elements 1, 3): two 8-byte (bf16: 4-byte) stores.
+              const long long cvox = TZYX >> 3;                                   // coarse voxels per channel
+              const int C = (int)(cat_bstride(p.out, si) / TZYX);                 // channels of the slice
+              const int c = n - cat_cbeg(p.out, si);
+              const int f0 = ((oz & 1) * 2 + (oy & 1)) * 2;
+              const long long co = ((long long)b * 8 * C + (long long)f0 * C + c) * cvox +
+                                   ((long long)(oz >> 1) * (p.TY_ >> 1) + (oy >> 1)) * (p.TX_ >> 1) + (ox >> 1);
+              if constexpr (BF) {
+                __bf16* d0 = reinterpret_cast<__bf16*>(base) + co;
+                const unsigned e02 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) << 16);
+                const unsigned e13 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+                *reinterpret_cast<unsigned*>(d0) = e02;
+                *reinterpret_cast<unsigned*>(d0 + (long long)C * cvox) = e13;
+              } else {
+                *reinterpret_cast<float2*>(base + co) = float2{v[0], v[2]};
+                *reinterpret_cast<float2*>(base + co + (long long)C * cvox) = float2{v[1], v[3]};
+              }
+              continue;
             }
           }
           store4(base, o, v, p.out_f32 != 0);
@@ -1213,6 +1257,7 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
     pair = pair && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 3 : 15)) == 0;
     bquad = bquad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 7) == 0;
   }
+  SR3D_CHECK(!p.act_unsh || (p.X % 4 == 0 && p.Z % 2 == 0 && p.Y % 2 == 0), SR3D_E_ARG, "split-f16 conv: the unshuffle-fused slice needs an even grid with X %% 4 == 0");
   // the 16-byte epilogue: rows of 4 x-neighbours, every destination (and the tensors read or written next to it) aligned
   {
     const uintptr_t am = (bf && !p.out_f32) ? 7 : 15;
@@ -1225,6 +1270,7 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
       vec = vec && (reinterpret_cast<uintptr_t>(p.act_y) & (bf ? 7 : 15)) == 0;
     }
     p.vec_epi = vec ? 1 : 0;
+    SR3D_CHECK(!p.act_unsh || vec, SR3D_E_ARG, "split-f16 conv: the unshuffle-fused slice needs the 16-byte epilogue (aligned tensors)");
   }
   if (!bf) return pair ? hconv_launch_t<false, 1>(p, B, n2, n1, nsp, st) : hconv_launch_t<false, 0>(p, B, n2, n1, nsp, st);
   if (pair && bquad) return hconv_launch_t<true, 2>(p, B, n2, n1, nsp, st);

@@ -308,6 +308,13 @@ struct SmallFwdParams {
   float* y;            // (B, N, Z, Y, X), or N channels inside a wider tensor (y_bstride)
   long long y_bstride; // elements between samples of y
   int act;
+  // remainder rows of an input gradient whose destination slice has the activation backward fused (sr3d_conv3d_bwd_data_act):
+  // act_y = the producing layer's output at the first of these channels (same strides as y); the result is multiplied by
+  // lrelu'(act_y), its maximum goes to act_amax[64]; unsh_C > 0: y is that slice's buffer and receives the values in the
+  // producer's SHUFFLED layout, channel ((fz*2+fy)*2+fx) * unsh_C + unsh_c0 + n on the coarse grid (needs X % 4 == 0)
+  const float* act_y;
+  unsigned* act_amax;
+  int unsh_C, unsh_c0;
 };
 
 __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p) {
@@ -392,15 +399,35 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
   }
 
   const int gz = z0 + tz, gy = y0 + ty, gx = x0 + 4 * xq;
+  float amax_act = 0.f;
   if (gz < p.Z && gy < p.Y) {
 #pragma unroll
     for (int n = 0; n < 4; n++) {
       if (n >= p.N) break;
       const float bv = p.bias ? p.bias[n] : 0.f;
-      float* o = p.y + (long long)b * p.y_bstride + ((long long)n * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
+      const long long fine = (long long)b * p.y_bstride + ((long long)n * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
+      float* o = p.y + fine;
       float r[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) r[i] = act_apply(acc[i][n] + bv, p.act);
+      if (p.act_y != nullptr) {      // (fused activation backward: X % 4 == 0 and aligned tensors, checked by the caller)
+        if (gx + 3 >= p.X) continue;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.act_y + fine);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          r[i] = yv[i] > 0.f ? r[i] : 0.01f * r[i];
+          amax_act = fmaxf(amax_act, fabsf(r[i]));
+        }
+        if (p.unsh_C > 0) {
+          const long long cvox = ((long long)p.Z * p.Y * p.X) >> 3;
+          const int f0 = ((gz & 1) * 2 + (gy & 1)) * 2;
+          float* d0 = p.y + (long long)b * p.y_bstride + ((long long)f0 * p.unsh_C + p.unsh_c0 + n) * cvox +
+                      ((long long)(gz >> 1) * (p.Y >> 1) + (gy >> 1)) * (p.X >> 1) + (gx >> 1);
+          *reinterpret_cast<float2*>(d0) = float2{r[0], r[2]};
+          *reinterpret_cast<float2*>(d0 + (long long)p.unsh_C * cvox) = float2{r[1], r[3]};
+          continue;
+        }
+      }
       if (vec && gx + 3 < p.X) {
         *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]};
       } else {
@@ -409,6 +436,11 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
           if (gx + i < p.X) o[i] = r[i];
       }
     }
+  }
+  if (p.act_amax != nullptr) {   // (kernel-argument condition: uniform)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax_act = fmaxf(amax_act, __shfl_xor(amax_act, off, 64));
+    if (lane == 0 && amax_act > 0.f) atomicMax(p.act_amax + (blockIdx.x & 63), __float_as_uint(amax_act));
   }
 }
 
@@ -939,15 +971,22 @@ static int bwd_rem_rows(const sr3d_conv_desc_t* d, int rows, int last_channels) 
 }
 // the fused activation epilogue exists in the split-f16 / bf16 stride-1 kernel only, and not for a slice whose last
 // channels leave for the VALU remainder kernel
-static bool bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice) {
+static bool bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, bool unsh = false) {
   if (check_desc(d) != SR3D_OK || d->stride != 1 || act_slice < 0 || act_slice >= n_dst || dx_dsts == nullptr) return false;
   if (dx_dsts[act_slice].ptr == nullptr) return false;
+  if (unsh) {   // the producer's shuffled layout is written by the 16-byte epilogues only (MFMA kernel and VALU remainder kernel)
+    if (d->X % 4 != 0 || d->Y % 2 != 0 || d->Z % 2 != 0 || getenv("SR3D_HCONV_SCALAR_EPILOGUE") != nullptr) return false;
+    for (int i = 0; i < n_dst; i++)
+      if (reinterpret_cast<uintptr_t>(dx_dsts[i].ptr) & 15) return false;
+    return use_hconv(d, n_dy * d->Cout, bwd_rows(dx_dsts, n_dst));
+  }
   const int rows = bwd_rows(dx_dsts, n_dst);
   if (!use_hconv(d, n_dy * d->Cout, rows)) return false;
   int last = -1;
   for (int i = 0; i < n_dst; i++)
     if (dx_dsts[i].ptr) last = i;
-  return !(last == act_slice && bwd_rem_rows(d, rows, dx_dsts[last].channels) > 0);
+  // (remainder rows of the fused slice take the VALU kernel's fused epilogue: 4 x-neighbours per thread)
+  return !(last == act_slice && bwd_rem_rows(d, rows, dx_dsts[last].channels) > 0 && d->X % 4 != 0);
 }
 
 size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy) {
@@ -969,7 +1008,7 @@ size_t sr3d_conv3d_bwd_data_workspace_bytes(const sr3d_conv_desc_t* d, int n_dy)
 // (sr3d_conv3d_bwd_data_act) -- only the split-f16 / bf16 stride-1 kernel has that epilogue
 static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
                          const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, void* workspace,
-                         size_t workspace_bytes, void* stream, int act_slice, const void* act_y, void* act_absmax) {
+                         size_t workspace_bytes, void* stream, int act_slice, const void* act_y, void* act_absmax, bool act_unsh = false) {
   if (int rc = check_desc(d)) return rc;
   SR3D_CHECK(w_feat && workspace && dx_dsts, SR3D_E_ARG, "conv3d_bwd_data: null pointer");
   SR3D_CHECK(n_dy == 1 || (n_dy == 2 && w_gate), SR3D_E_ARG, "conv3d_bwd_data: n_dy must be 1, or 2 with w_gate");
@@ -1017,7 +1056,7 @@ static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   float* image = (float*)workspace;
 
   const bool hconv = use_hconv(d, K, rows);
-  SR3D_CHECK(act_slice < 0 || (act_nn >= 0 && act_y != nullptr && bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice)), SR3D_E_ARG,
+  SR3D_CHECK(act_slice < 0 || (act_nn >= 0 && act_y != nullptr && bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice, act_unsh)), SR3D_E_ARG,
              "conv3d_bwd_data_act: this launch has no fused activation epilogue (ask sr3d_conv3d_bwd_data_fuses_act first)");
   if (hconv || (use_wino(d) && K <= SR3D_WINO_MAX_K)) {
     // 1..4 gradient rows beyond a multiple of 64 (e.g. 193 = 3 * 64 + 1) would cost a whole 32-row Winograd tile per
@@ -1033,7 +1072,7 @@ static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
       q.K = K, q.N = main_rows, q.Z = d->Z, q.Y = d->Y, q.X = d->X;
       q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
       q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
-      if (act_nn >= 0) q.act_slice1 = act_nn + 1, q.act_y = act_y, q.act_amax = is_bf(d) ? nullptr : (unsigned*)act_absmax;
+      if (act_nn >= 0) q.act_slice1 = act_nn + 1, q.act_y = act_y, q.act_amax = is_bf(d) ? nullptr : (unsigned*)act_absmax, q.act_unsh = act_unsh ? 1 : 0;
       if (int rc = sr3d_hconv_pack(pk.kind, d->Cout, d->Cin, main_rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
       if (int rc = sr3d_hconv_launch(q, image, d->B, is_bf(d), st)) return rc;
       wsm = (float*)((unsigned char*)image + ((sr3d_hconv_image_bytes(main_rows, K, is_bf(d)) + 255) & ~(size_t)255));
@@ -1058,6 +1097,11 @@ static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
       const long long vox = (long long)d->Z * d->Y * d->X;
       sq.w = wsm, sq.bias = nullptr, sq.act = SR3D_ACT_NONE;
       sq.y = (float*)last.ptr + (long long)(last.channels - rem) * vox, sq.y_bstride = (long long)last.channels * vox;
+      if (act_nn == nn - 1) {   // the remainder rows belong to the activation-fused slice
+        sq.act_y = (const float*)act_y + (long long)(last.channels - rem) * vox;
+        sq.act_amax = (unsigned*)act_absmax;
+        if (act_unsh) sq.y = (float*)last.ptr, sq.unsh_C = last.channels, sq.unsh_c0 = last.channels - rem;
+      }
       SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_bwd_data: batch too large");
       hipLaunchKernelGGL(smalln_fwd_kernel, dim3(sq.ntz * sq.nty * sq.ntx, d->B), dim3(256), 0, st, sq);
       SR3D_HIP(hipGetLastError());
@@ -1111,16 +1155,19 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
   return bwd_data_impl(d, dy_srcs, n_dy, w_feat, w_gate, dx_dsts, n_dst, workspace, workspace_bytes, stream, -1, nullptr, nullptr);
 }
 
-int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice) {
-  return bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice) ? 1 : 0;
+int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, int act) {
+  if ((act & ~SR3D_ACT_UNSHUFFLE) != SR3D_ACT_LRELU) return 0;
+  return bwd_data_fuses_act(d, n_dy, dx_dsts, n_dst, act_slice, (act & SR3D_ACT_UNSHUFFLE) != 0) ? 1 : 0;
 }
 
 int sr3d_conv3d_bwd_data_act(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
                              const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, const void* act_y,
                              int act, void* act_absmax, void* workspace, size_t workspace_bytes, void* stream) {
+  const bool unsh = (act & SR3D_ACT_UNSHUFFLE) != 0;
+  act &= ~SR3D_ACT_UNSHUFFLE;
   SR3D_CHECK(act == SR3D_ACT_LRELU, SR3D_E_ARG, "conv3d_bwd_data_act: the fused epilogue is LeakyReLU'(y) (got act %d)", act);
   SR3D_CHECK(act_slice >= 0 && act_slice < n_dst && act_y != nullptr, SR3D_E_ARG, "conv3d_bwd_data_act: bad act_slice / act_y");
-  return bwd_data_impl(d, dy_srcs, n_dy, w_feat, w_gate, dx_dsts, n_dst, workspace, workspace_bytes, stream, act_slice, act_y, act_absmax);
+  return bwd_data_impl(d, dy_srcs, n_dy, w_feat, w_gate, dx_dsts, n_dst, workspace, workspace_bytes, stream, act_slice, act_y, act_absmax, unsh);
 }
 
 }  // extern "C"

@@ -54,7 +54,8 @@ class UpBlock(nn.Module):
 
     def forward(self, x1, x2, defer_act_bwd: bool = False) -> torch.Tensor:
         """``defer_act_bwd``: set by UNetSR, where every LeakyReLU output of this block feeds exactly one convolution"""
-        x3 = ops.conv3d_act(_as_list(x1), self.up[0].weight, self.up[0].bias, act="lrelu", stride=1, unshuffle=True)
+        x3 = ops.conv3d_act(_as_list(x1), self.up[0].weight, self.up[0].bias, act="lrelu", stride=1, unshuffle=True,
+                            defer_act_bwd=defer_act_bwd)
         y = _as_list(x2) + [x3]
         for layer in self.convs:
             y = layer(y, defer_act_bwd=defer_act_bwd)

@@ -137,10 +137,10 @@ class _ActBox:
     """Shared by a LeakyReLU layer that deferred its activation backward (``defer_act_bwd=True``) and the convolution that
     consumes its output: when the consumer's input-gradient kernel has the fused epilogue (sr3d_conv3d_bwd_data_act), what
     it hands back through autograd is already dL/dpre of the producer (``done``), with max |dL/dpre| in ``amax``."""
-    __slots__ = ("done", "amax")
+    __slots__ = ("done", "amax", "unshuffle")
 
-    def __init__(self):
-        self.done, self.amax = False, None
+    def __init__(self, unshuffle: bool = False):
+        self.done, self.amax, self.unshuffle = False, None, unshuffle
 
 
 def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate, boxes=None) -> List[Optional[torch.Tensor]]:
@@ -154,12 +154,15 @@ def _bwd_data(desc: L.ConvDesc, srcs, needs: Sequence[bool], dys, w_feat, w_gate
     dst_arr = L.slices(dsts, "dx_dsts", dt)
     # activation backward of a source layer fused into the epilogue (one slice at most: srcs[i] IS that layer's output y)
     fuse = next((i for i, (bx, n) in enumerate(zip(boxes or [], needs)) if bx is not None and n), None) if FUSE_ACT_BWD else None
-    if fuse is not None and L.lib.sr3d_conv3d_bwd_data_fuses_act(C.byref(desc), len(dys), dst_arr, len(dsts), fuse):
+    act = L.ACT_CODE["lrelu"] | (L.ACT_UNSHUFFLE if (fuse is not None and boxes[fuse].unshuffle) else 0)
+    if fuse is not None and L.lib.sr3d_conv3d_bwd_data_fuses_act(C.byref(desc), len(dys), dst_arr, len(dsts), fuse, act):
         box = boxes[fuse]
         box.amax = _amax_slots(1, dys[0]) if dt == torch.float32 else None
+        # (an unshuffle producer: outs[fuse] has the slice's shape for autograd's sake, but holds that layer's dL/dpre in ITS
+        #  layout -- 8 C channels on the coarse grid, the same number of elements; Conv3dAct.backward views it back)
         L.check(L.lib.sr3d_conv3d_bwd_data_act(C.byref(desc), L.slices(dys, "dy_srcs", dt), len(dys), L.dev_ptr(w_feat),
                                                L.dev_ptr(w_gate), dst_arr, len(dsts), fuse, L.dev_ptr(srcs[fuse], "act_y", dt),
-                                               L.ACT_CODE["lrelu"], _raw_ptr(box.amax), L.dev_ptr(ws), nbytes, L.stream_ptr()),
+                                               act, _raw_ptr(box.amax), L.dev_ptr(ws), nbytes, L.stream_ptr()),
                 "sr3d_conv3d_bwd_data_act")
         box.done = True
         return outs
@@ -214,8 +217,8 @@ class Conv3dAct(torch.autograd.Function):
         # `defer_act_bwd`: the caller guarantees that y feeds exactly ONE engine convolution; that layer's input
         # gradient then stores dL/dy * lrelu'(y) directly and this layer's lrelu_bwd pass never runs (model/unet.py)
         ctx.act_box = None
-        if defer_act_bwd and act == "lrelu" and not unshuffle and any(ctx.needs_input_grad):
-            ctx.act_box = y._sr3d_act_box = _ActBox()
+        if defer_act_bwd and act == "lrelu" and any(ctx.needs_input_grad):
+            ctx.act_box = y._sr3d_act_box = _ActBox(unshuffle=bool(unshuffle))
         return y
 
     @staticmethod
@@ -229,6 +232,9 @@ class Conv3dAct(torch.autograd.Function):
         box = ctx.act_box
         if box is not None and box.done:      # the consumer's input-gradient epilogue already applied lrelu'(y)
             dpre, dy_amax = dy, (box.amax if dy_amax is not None else None)
+            if ctx.unshuffle:                 # ... and wrote it in THIS layer's layout: 8 C channels on the coarse grid
+                B, c, z2, y2, x2 = dy.shape
+                dpre = dy.view(B, 8 * c, z2 // 2, y2 // 2, x2 // 2)
             box.done, box.amax = False, None
         elif ctx.unshuffle:
             B, c, z2, y2, x2 = dy.shape

@@ -50,7 +50,8 @@ enum { SR3D_DTYPE_F32 = 0, SR3D_DTYPE_BF16 = 1 };
 /* activations fused into conv epilogues (custom_conv.py:111-126, unet.py:35,84,105) */
 enum { SR3D_ACT_NONE = 0, SR3D_ACT_RELU = 1, SR3D_ACT_LRELU = 2 /* slope 0.01 */,
        SR3D_ACT_OUT_F32 = 0x100 /* flag OR-ed to `act` of sr3d_conv3d_fwd: see there */,
-       SR3D_ACT_FROM_Y = 0x200 /* flag OR-ed to `act` of sr3d_gated_act_bwd: see there */ };
+       SR3D_ACT_FROM_Y = 0x200 /* flag OR-ed to `act` of sr3d_gated_act_bwd: see there */,
+       SR3D_ACT_UNSHUFFLE = 0x400 /* flag OR-ed to `act` of sr3d_conv3d_bwd_data_act / _fuses_act: see there */ };
 
 /* One operand of a virtual channel concatenation (replaces torch.cat at
  * unet.py:255-293): `channels` channels of a (B, channels, Z, Y, X) tensor.
@@ -134,8 +135,12 @@ int sr3d_conv3d_bwd_data(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
  * is stored there is dL/dy * lrelu'(y) = dL/dpre of THAT layer -- its lrelu_bwd pass (autograd's leaky_relu_backward,
  * pytorch/model/unet.py:72-97,192-199) never runs; in fp32 the stored values are bit-identical to sr3d_conv3d_bwd_data followed
  * by sr3d_lrelu_bwd.  act_absmax (optional, [64] zeroed words, fp32 storage): max |stored| for that layer's weight gradient.
- * Only launches for which sr3d_conv3d_bwd_data_fuses_act answers 1 have this epilogue (the split-f16 / bf16 stride-1 kernel). */
-int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice);
+ * Only launches for which sr3d_conv3d_bwd_data_fuses_act answers 1 have this epilogue (the split-f16 / bf16 stride-1 kernel).
+ * act | SR3D_ACT_UNSHUFFLE: the slice is the voxel-UNSHUFFLED output of a conv + LeakyReLU layer (UpBlock.up, unet.py:99-108):
+ * act_y has the slice's own (fine-grid) layout, and dx_dsts[act_slice].ptr -- a buffer with the slice's element count --
+ * receives dL/dpre of THAT layer in ITS layout, (B, 8 C, Z/2, Y/2, X/2) for a slice of C channels (what
+ * sr3d_unshuffle_lrelu_bwd would have produced).  Needs X % 4 == 0. */
+int sr3d_conv3d_bwd_data_fuses_act(const sr3d_conv_desc_t* d, int n_dy, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, int act);
 int sr3d_conv3d_bwd_data_act(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs, int n_dy, const void* w_feat,
                              const void* w_gate, const sr3d_slice_t* dx_dsts, int n_dst, int act_slice, const void* act_y,
                              int act, void* act_absmax, void* workspace, size_t workspace_bytes, void* stream);

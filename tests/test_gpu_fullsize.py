@@ -452,7 +452,7 @@ def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeyp
     # up1.convs.0 / .1 deferred their activation backward: the gradient that reaches them through autograd is
     # already dL/dpre, written by the consumer's input-gradient epilogue; the window check below holds it against
     # conv_transpose(...) * lrelu'(y) of the oracle, the weight gradients against the tap contraction of that dL/dpre
-    assert by_name["up1.convs.1.conv"]["deferred"] and by_name["up1.convs.0.conv"]["deferred"] and not by_name["up1.up.0"]["deferred"]
+    assert by_name["up1.convs.1.conv"]["deferred"] and by_name["up1.convs.0.conv"]["deferred"] and by_name["up1.up.0"]["deferred"]
     for n in heavy:
         c = by_name[n]
         out, dy = c["out"].detach(), dys[n]
@@ -462,7 +462,12 @@ def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeyp
             #  exactly 0 on this data, and the engine decides on the same stored y)
         else:
             dpre = dy
-        if c["unshuffle"]:
+        if c["unshuffle"] and c["deferred"]:
+            # the consumer wrote up1.up.0's dL/dpre in THAT layer's layout (8 C channels on the coarse grid) into a buffer that
+            # autograd sees with the unshuffled shape: same bytes, viewed back
+            B_, c_, z2, y2, x2 = dy.shape
+            dpre = dy.contiguous().view(B_, 8 * c_, z2 // 2, y2 // 2, x2 // 2)
+        elif c["unshuffle"]:
             dpre = R.shuffle_voxels(dpre, 2)
         xin = torch.cat(c["srcs"], 1)
         dw_ref, db_ref = R.conv3d_weight_grad_by_taps(xin, dpre)
@@ -481,6 +486,9 @@ def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeyp
             prod = next((k for k in calls if k["out"] is obj), None)
             if prod is not None and prod["name"] in dys and obj.requires_grad:
                 got_full = dys[prod["name"]]            # the gradient that reached the producer = this layer's dx
+                if prod["deferred"] and prod["unshuffle"]:      # (stored in the producer's shuffled layout: back to the fine grid)
+                    B_, c_, z2, y2, x2 = got_full.shape
+                    got_full = R.unshuffle_voxels(got_full.contiguous().view(B_, 8 * c_, z2 // 2, y2 // 2, x2 // 2), 2)
                 for lo in [(0, 0, 0), tuple(g - d for g, d in zip(grid, (3, 5, 36))), (grid[0] // 2, grid[1] // 2 + 1, grid[2] // 2 - 9)]:
                     hi = tuple(min(g, l + d) for g, l, d in zip(grid, lo, (3, 5, 36)))
                     dlo, dhi = [max(0, l - 1) for l in lo], [min(g, h + 1) for h, g in zip(hi, grid)]

@@ -327,20 +327,27 @@ def test_fused_activation_backward_equals_the_separate_pass_bit_for_bit(eng, mon
         monkeypatch.setattr(eng.ops, "FUSE_ACT_BWD", fused)
         torch.manual_seed(3)
         model = eng.make_model(cfg).to(DEV)
-        calls = {"act": 0}
-        orig = eng._lib.lib.sr3d_lrelu_bwd
+        calls = {"act": 0, "unsh": 0}
+        orig, orig_u = eng._lib.lib.sr3d_lrelu_bwd, eng._lib.lib.sr3d_unshuffle_lrelu_bwd
 
         def counted(*a, _orig=orig):
             calls["act"] += 1
             return _orig(*a)
+
+        def counted_u(*a, _orig=orig_u):
+            calls["unsh"] += 1
+            return _orig(*a)
         monkeypatch.setattr(eng._lib.lib, "sr3d_lrelu_bwd", counted)
+        monkeypatch.setattr(eng._lib.lib, "sr3d_unshuffle_lrelu_bwd", counted_u)
         loss = eng.make_loss(cfg)(model(x, b), y, b)
         loss.backward()
         torch.cuda.synchronize()
         monkeypatch.setattr(eng._lib.lib, "sr3d_lrelu_bwd", orig)
-        res[fused] = ({k: p.grad.detach().clone() for k, p in model.named_parameters()}, calls["act"], float(loss.detach()))
+        monkeypatch.setattr(eng._lib.lib, "sr3d_unshuffle_lrelu_bwd", orig_u)
+        res[fused] = ({k: p.grad.detach().clone() for k, p in model.named_parameters()}, (calls["act"], calls["unsh"]), float(loss.detach()))
     assert res[True][2] == res[False][2]
-    # 11 plain LeakyReLU layers (3 latent + 8 UpBlock convs): all of them fused away, none on the reference path
-    assert res[False][1] == 11 and res[True][1] == 0, (res[True][1], res[False][1])
+    # 11 plain LeakyReLU layers (3 latent + 8 UpBlock convs) and the 4 unshuffle layers (UpBlock.up): all fused away where the
+    # grid allows it (the unshuffle form needs X % 4 == 0 on the consumer's grid: HR x 64, 32, 16, 8 -> all four levels)
+    assert res[False][1] == (11, 4) and res[True][1] == (0, 0), (res[True][1], res[False][1])
     for k, g in res[True][0].items():
         assert torch.equal(g, res[False][0][k]), k
