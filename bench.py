@@ -260,6 +260,9 @@ def main():
     ap.add_argument("--lr-grid", type=int, nargs=3, default=[20, 80, 80], metavar=("Z", "Y", "X"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short second workload")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
+                    help="activation storage of the PRIMARY workload (bf16: engine extension, BASELINE configs[4]; for profiling -- "
+                         "the default line is fp32, the reference's precision)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step into a hipGraph and time replays (no per-kernel breakdown)")
     ap.add_argument("--force-dist", action="store_true",
@@ -288,7 +291,7 @@ def main():
     batch = args.batch if args.batch is not None else (1 if world == 1 else 4)
     loss_name = args.loss if args.loss is not None else ("l1" if world == 1 else "mixed")
     m = measure(sr3d_amd, L, dev, rank, world, use_dist, batch, loss_name, args.lr_grid, args.steps, args.warmup,
-                graph=args.graph, breakdown_steps=0 if args.graph else 2)
+                graph=args.graph, breakdown_steps=0 if args.graph else 2, storage=args.storage)
     leg_errors = {}
 
     def attached(name, fn):
@@ -400,14 +403,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32 (2 x fp16-split MFMA products, fp32 accumulate)" if split else "fp32",
+            "dtype": ("bf16 storage + bf16 MFMA, fp32 accumulate / master weights / Adam" if args.storage == "bf16" else
+                      "fp32 (2 x fp16-split MFMA products, fp32 accumulate)" if split else "fp32"),
             "dtype_note": ("storage, accumulation and results are fp32; the products of the chip-filling convolutions (forward, "
                            "input gradient, stride-1 weight gradient) are 3 f16 MFMAs on fp32 operands split exactly into two "
                            "fp16 halves (error 2^-22 per operand; every parity test at 1e-5, measured layer error 4e-7 = that of "
                            "the fp32 MFMA kernels); SR3D_SPLIT_F16=0 computes every product on the fp32 MFMA: fp32_mfma_only"
                            if split else "every product on the fp32 MFMA"),
             "data": "synthetic",
-            "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world) +
+            "config": {"workload": workload_name(args.lr_grid, hr, batch, loss_name, world, args.storage) +
                        (" [hipGraph replay]" if args.graph else ""),
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
