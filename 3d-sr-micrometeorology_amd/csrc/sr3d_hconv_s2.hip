@@ -56,8 +56,8 @@ __host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
 // vector-memory instructions (~22 cycles of the texture path per wave instruction: 320 per chunk pair of a CU against
 // 2600 cycles of MFMAs); a lane then holds 4 voxels x 4 channels and writes 8-byte half pieces.
 template <int RT, int MODE, bool BF, bool QD = false>
-__global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hconv_s2_kernel(const SrHconvS2Params p) {   // (that one form needs 219 VGPRs)
-  static_assert(!QD || (MODE == 2 && !BF), "quad loads: the fp32 input gradient");
+__global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2 && !QD) ? 2 : 3) void hconv_s2_kernel(const SrHconvS2Params p) {   // (that one form needs 219 VGPRs)
+  static_assert(!QD || MODE == 2, "quad loads: the input gradient (fp32: 16-byte quads; bf16, round 4: 8-byte quads)");
   static_assert(HNR == 4, "the counted wait behind phase 0 assumes 8 * HNR = 32 raw-row loads");
   using G = SGeo<RT, BF>;
   constexpr int NP = G::NP;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hco
       const int gz = z0 + hz, gy = y0 + hy, gx = x0 + 4 * q;
       const bool task = t < UZ * UY * QPR;
       const bool ok = task && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;   // IX % 4 == 0: all four or none
-      qoff[r] = ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * 4u : 0xffffffffu;
+      qoff[r] = ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ : 0xffffffffu;
       qwr[r] = ((hz * HHY + hy) * HHX + 4 * q) * 16;
       qmask[r] = !task ? 0 : (q == QPR - 1 ? 1 : 15);
     }
@@ -179,9 +179,15 @@ __global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hco
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
         for (int r = 0; r < QNR; r++) {
-          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, qoff[r], 0, 0);
+          if constexpr (BF) {   // 4 bf16 x-neighbours: two dwords (voxels 0|1, 2|3)
+            const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, qoff[r], 0, 0);
+            rawq[r][c * 4 + 0] = __builtin_bit_cast(float, (unsigned)t[0]);
+            rawq[r][c * 4 + 1] = __builtin_bit_cast(float, (unsigned)t[1]);
+          } else {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, qoff[r], 0, 0);
 #pragma unroll
-          for (int v = 0; v < 4; v++) rawq[r][c * 4 + v] = __builtin_bit_cast(float, (unsigned)t[v]);
+            for (int v = 0; v < 4; v++) rawq[r][c * 4 + v] = __builtin_bit_cast(float, (unsigned)t[v]);
+          }
         }
       }
       return;
@@ -266,6 +272,22 @@ __global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2) ? 2 : 3) void hco
     return s_c < s_run ? s_c : s_run;
   };
   auto split_and_write = [&](const float in_mult) {
+    if constexpr (QD && BF) {   // the same half pieces, packed instead of split: (ch 0 | ch 1), (ch 2 | ch 3) of voxel v
+      unsigned char* H0 = Hs + (wave >> 1) * HPLANE + (wave & 1) * 8;
+#pragma unroll
+      for (int r = 0; r < QNR; r++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const unsigned sel = (v & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of the two dwords
+          const unsigned a0 = __builtin_bit_cast(unsigned, rawq[r][0 * 4 + (v >> 1)]), a1 = __builtin_bit_cast(unsigned, rawq[r][1 * 4 + (v >> 1)]);
+          const unsigned a2 = __builtin_bit_cast(unsigned, rawq[r][2 * 4 + (v >> 1)]), a3 = __builtin_bit_cast(unsigned, rawq[r][3 * 4 + (v >> 1)]);
+          if ((qmask[r] >> v) & 1) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(H0 + qwr[r] + v * 16) = u32x2{__builtin_amdgcn_perm(a1, a0, sel), __builtin_amdgcn_perm(a3, a2, sel)};
+          }
+        }
+      return;
+    }
     if constexpr (QD) {   // channels 4 w .. 4 w + 3 = bytes 8 (w & 1) .. + 7 of the 16-byte piece of channel half w >> 1
       unsigned char* H0 = Hs + (wave >> 1) * HPLANE + (wave & 1) * 8;
 #pragma unroll
@@ -617,10 +639,8 @@ int set_attrs() {
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-  if constexpr (!BF) {
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-  }
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   return SR3D_OK;
 }
 
@@ -725,13 +745,14 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
     const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
     if (mode == 1)
       bf ? launch_rt<1, true>(rt, grid, st, q) : launch_rt<1, false>(rt, grid, st, q);
-    else if (bf)
-      launch_rt<2, true>(rt, grid, st, q);
     else {
-      // quad loads of the dY rows: IX % 4 == 0 and 16-byte aligned tensors (then every channel row is)
+      // quad loads of the dY rows: IX % 4 == 0 and 16-byte (bf16: 8-byte) aligned tensors (then every channel row is)
       bool quad = p.IX % 4 == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr;
-      for (int i = 0; i < p.in.n; i++) quad = quad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 15) == 0;
-      quad ? launch_rt<2, false, true>(rt, grid, st, q) : launch_rt<2, false, false>(rt, grid, st, q);
+      for (int i = 0; i < p.in.n; i++) quad = quad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 7 : 15)) == 0;
+      if (bf)
+        quad ? launch_rt<2, true, true>(rt, grid, st, q) : launch_rt<2, true, false>(rt, grid, st, q);
+      else
+        quad ? launch_rt<2, false, true>(rt, grid, st, q) : launch_rt<2, false, false>(rt, grid, st, q);
     }
   }
   sr3d_prof_end(tok, st);
