@@ -20,6 +20,13 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#ifndef S2F_TPP_BF
+#define S2F_TPP_BF 3
+#endif
+#ifndef S2F_WGS_BF
+#define S2F_WGS_BF 3
+#endif
+
 namespace {
 
 
@@ -49,6 +56,67 @@ static_assert(3 * SGeo<2>::LDS <= 160 * 1024, "LDS budget: three workgroups per 
 //   MODE 2 (gradient): even: k = 1 at h = 0;  odd: i = 0 -> k = 0 at h = 1, i = 1 -> k = 2 at h = 0   (halo origin i0)
 __host__ __device__ inline int tap_h(int mode, int par, int i) { return mode == 1 ? (par ? i : 1) : (par ? 1 - i : 0); }
 __host__ __device__ inline int tap_k(int par, int i) { return par ? 2 * i : 1; }
+
+// accumulators -> destination: gated (forward) or plain (forward / the class `ocls` of the fine grid, input gradient)
+template <int RT, int MODE, bool BF>
+__device__ __forceinline__ void s2_epilogue(const SrHconvS2Params& p, f32x16 (&acc)[RT][2], const float out_mult, const int wave, const int lane,
+                                            const int b, const int nblk, const int ocls, const int z0, const int y0, const int x0,
+                                            const int TZ, const int TY, const int TX) {
+  const int ox = x0 + (lane & 31);
+  const int rblock = p.n_off + (p.nb_off + nblk) * 64;
+  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
+  if (ox >= TX) return;
+  if (MODE == 1 && p.epi == SR3D_EPI_GATED) {
+    if constexpr (RT == 2) {
+      const int cbase = rblock / 2 + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int vt = 2 * wave + j;
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+        if (oz >= TZ || oy >= TY) continue;
+        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2);
+          if (co < p.Cg) {
+            float f = acc[0][j][r] * out_mult;
+            if (p.bias) f += p.bias[co];
+            const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
+            const float s = 1.f / (1.f + expf(-g));
+            f = split_act(f, p.act);
+            const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
+            st_act<BF>(p.y, o, s * f);
+            if (p.save_f) st_act<BF>(p.save_f, o, f);
+            if (p.save_s) st_act<BF>(p.save_s, o, s);
+          }
+        }
+      }
+    }
+  } else {
+    const int so = MODE == 2 ? 2 : 1;
+    const int qz = MODE == 2 ? (ocls >> 2) & 1 : 0, qy = MODE == 2 ? (ocls >> 1) & 1 : 0, qx = MODE == 2 ? ocls & 1 : 0;
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        if (n >= p.N) continue;
+        const int si = cat_find(p.out, n);
+        float* base = cat_ptr(p.out, si);
+        if (base == nullptr) continue;
+        const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int vt = 2 * wave + j;
+          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+          if (oz < TZ && oy < TY)
+            st_act<BF>(base, boff + ((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx),
+                       split_act(acc[i][j][r] * out_mult + bv, p.act));
+        }
+      }
+  }
+}
 
 // QD (input gradient, fp32, IX % 4 == 0, 16-byte aligned tensors): the dY halo rows are contiguous in x and are fetched as
 // 16-byte QUADS: wave w stages channels 4w .. 4w + 3 of the chunk, a lane takes quad q of halo row (hz, hy) -- 15 rows x 9
@@ -463,60 +531,339 @@ __global__ __launch_bounds__(HNT, (BF && MODE == 2 && RT == 2 && !QD) ? 2 : 3) v
   }
   // ------------------------------------------------------------------ epilogue
   const float out_mult = ldexpf((!BF && (((NV - 1) >> S2FLIP_SH) & 1)) ? -1.f : 1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
-  const int ox = x0 + (lane & 31);
-  const int rblock = p.n_off + (p.nb_off + nblk) * 64;
-  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
-  if (ox >= TX) return;
-  if (MODE == 1 && p.epi == SR3D_EPI_GATED) {
-    if constexpr (RT == 2) {
-      const int cbase = rblock / 2 + 4 * (lane >> 5);
+  s2_epilogue<RT, MODE, BF>(p, acc, out_mult, wave, lane, b, nblk, ocls, z0, y0, x0, TZ, TY, TX);
+}
+
+// ---- FORWARD WITH BOTH X PARITIES PER LOAD (round 4; X % 4 == 0).  The class form above fetches every second element of a
+// row (4-byte loads at an 8-byte pitch: 32 wave instructions per 16-channel chunk for 12 .. 96 MFMAs, each cache line visited
+// by the even-x and by the odd-x class, cpc chunks apart) and was bound by the NUMBER of vector-memory instructions like the
+// input gradient before its quad loads -- in bf16 storage, with a third of the MFMAs, at 234 TFLOP/s against ~1000 at stride
+// 1.  Here a virtual chunk is ((pz, py), 16 channels) and holds BOTH x classes: the 3 x 5 halo rows of the pair are fetched
+// as 16-byte quads x = 2 x0 - 4 + 4 q .. + 3, q = 0 .. 16 (255 tasks = 2 rounds of 2 waves; wave w stages channel half w & 1
+// as in sr3d_hconv.hip: 16 loads per lane for what took 64), voxels 0 / 2 of a quad go to the even plane and 1 / 3 to the odd
+// plane (halo columns 2 q - 1 and 2 q), and the three x taps of a (kz, ky) -- k = 1 from the even plane, k = 0 and 2 from
+// the odd one -- follow each other as a flat tap list in phases of two taps (14 phases per 16 channels instead of 18).
+// LDS: two planes sets, 64 + 16 KB (split form, two workgroups per CU) or 32 + 8 KB (bf16, three).
+constexpr int FNR = 2, FQX = 17;
+template <int RT, bool BF>
+struct FGeo {
+  static constexpr int NP = BF ? 1 : 2;
+  // taps per phase (= per barrier): the split form has 12 MFMAs per tap and wave and LDS for two taps per buffer; bf16 has 4
+  // MFMAs per tap -- two taps were a barrier per 8 MFMAs --: three, the x taps of one (kz, ky) (down1.0 forward 2.35 ms with
+  // two, 2.20 with four, 2.15 with three and three workgroups per CU: profiles/r04ad_s2_fwd_variants.log)
+  static constexpr int TPP = BF ? S2F_TPP_BF : 2;
+  static constexpr int WBUF = TPP * NP * RT * 1024;
+  static constexpr int PXB = NP * 2 * HPLANE;       // one x class: [part][channel half] planes
+  static constexpr int HB = 2 * PXB;
+  static constexpr size_t LDS = HB + 2 * (size_t)WBUF;
+};
+static_assert(2 * FGeo<2, false>::LDS <= 160 * 1024 && 3 * FGeo<2, true>::LDS <= 160 * 1024, "LDS budget of the paired forward");
+__host__ __device__ inline int pair_taps(int pp) { return 3 * (1 + (pp >> 1)) * (1 + (pp & 1)); }   // pp = 2 pz + py
+__host__ __device__ inline int pair_taps_before(int pp) { return pp == 0 ? 0 : pp == 1 ? 3 : pp == 2 ? 9 : 15; }
+
+template <int RT, bool BF>
+__global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(const SrHconvS2Params p) {
+  using G = FGeo<RT, BF>;
+  constexpr int NP = G::NP;
+  constexpr int ESZ = BF ? 2 : 4;
+  constexpr int NRAW = 8 * FNR;                // raw-row loads per lane and chunk
+  constexpr int TPP = G::TPP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Hs = lds;
+  unsigned char* Ws = lds + G::HB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < HNT / 64);
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = v % p.nblk;
+  int blk = v / p.nblk;
+  const int tix = blk % p.ntx;
+  blk /= p.ntx;
+  const int tiy = blk % p.nty;
+  const int tiz = blk / p.nty;
+  const int b = blockIdx.y;
+  const int TZ = p.Z, TY = p.Y, TX = p.X;
+  const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
+  if (z0 >= TZ || y0 >= TY || x0 >= TX) return;
+  const long long IZYX = (long long)p.IZ * p.IY * p.IX;
+  const int chan_bytes = (int)(IZYX * ESZ);
+
+  int sw = BF ? 0 : split_scale_exp(*p.absmax_w);
+  if (sw == kSplitScaleNone) sw = 0;
+  float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
+
+  // ---- staging geometry: quad q of halo row (hz, hy); fbase = byte offset for (pz, py) = (0, 0), bit pp of fmask = the
+  // row of pair pp lies inside the grid (IX % 4 == 0: a quad is inside or outside as a whole)
+  const int sh = wave & 1;
+  unsigned fbase[FNR], fmask[FNR];
+  int fwr[FNR], fvox[FNR];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int vt = 2 * wave + j;
-        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-        if (oz >= TZ || oy >= TY) continue;
-        const long long sp = ((long long)oz * p.TY_ + oy) * p.TX_ + ox;
+  for (int r = 0; r < FNR; r++) {
+    const int t = (r * 2 + (wave >> 1)) * 64 + lane;
+    const int row = t / FQX, q = t - row * FQX;
+    const int hz = row / UY, hy = row - hz * UY;
+    const bool task = t < UZ * UY * FQX;
+    const int gz = 2 * (z0 - 1 + hz), gy = 2 * (y0 - 1 + hy), gx = 2 * x0 - 4 + 4 * q;
+    const bool okx = task && (unsigned)gx < (unsigned)p.IX;
+    unsigned m = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int co = cbase + (r & 3) + 8 * (r >> 2);
-          if (co < p.Cg) {
-            float f = acc[0][j][r] * out_mult;
-            if (p.bias) f += p.bias[co];
-            const float g = acc[1][j][r] * out_mult + (p.bias2 ? p.bias2[co] : 0.f);
-            const float s = 1.f / (1.f + expf(-g));
-            f = split_act(f, p.act);
-            const long long o = ((long long)b * p.Cg + co) * TZYX + sp;
-            st_act<BF>(p.y, o, s * f);
-            if (p.save_f) st_act<BF>(p.save_f, o, f);
-            if (p.save_s) st_act<BF>(p.save_s, o, s);
-          }
+    for (int pp = 0; pp < 4; pp++)
+      m |= (okx && (unsigned)(gz + (pp >> 1)) < (unsigned)p.IZ && (unsigned)(gy + (pp & 1)) < (unsigned)p.IY) ? (1u << pp) : 0u;
+    fmask[r] = m;
+    fbase[r] = (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ;   // (wraps at the borders; used only where a bit is set)
+    fwr[r] = ((hz * HHY + hy) * HHX + 2 * q - 1) * 16;                       // halo column 2 q - 1 (voxels 0, 1); voxels 2, 3: + 16
+    fvox[r] = !task ? 0 : (q == 0 ? 8 : 15);                                 // q = 0: only x = 2 x0 - 1 (odd plane, column 0)
+  }
+
+#define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
+  unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
+#undef SR3D_SLICE_BASE
+  int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
+  split_pin_scalar(sb0), split_pin_scalar(sb1), split_pin_scalar(sb2), split_pin_scalar(sb3);
+  split_pin_scalar(cb0), split_pin_scalar(cb1), split_pin_scalar(cb2), split_pin_scalar(cb3);
+  unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
+  int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
+  split_pin_scalar(dsb1), split_pin_scalar(dsb2), split_pin_scalar(dsb3), split_pin_scalar(dcb1), split_pin_scalar(dcb2), split_pin_scalar(dcb3);
+  auto slice_of = [&](const int gc) { return (gc >= cb1) + (gc >= cb2) + (gc >= cb3); };
+  auto chan_base = [&](const int gc) {
+    const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
+    const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
+    const int c0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
+    return base + (unsigned long long)(unsigned)(gc - c0) * (unsigned long long)(unsigned)chan_bytes;
+  };
+
+  const int cpc = p.nchunks;
+  const int NV = 4 * cpc;                     // virtual chunk = pair * cpc + 16-channel chunk
+  constexpr int RW = BF ? 16 : 32;            // fp32: [channel][voxel of the quad]; bf16: [channel][dword: voxels (0, 1) | (2, 3)]
+  float raw[FNR][RW];
+  auto load_raw = [&](const bool live, const int pp, const int cc) {
+    const unsigned cdelta = (unsigned)(((pp >> 1) * p.IY + (pp & 1)) * p.IX) * (unsigned)ESZ;   // wave-uniform
+    unsigned so[FNR];
+#pragma unroll
+    for (int r = 0; r < FNR; r++) so[r] = ((fmask[r] >> pp) & 1u) ? fbase[r] + cdelta : 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gc = cc * HKC + sh * 8 + c;   // wave-uniform
+      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < FNR; r++) {
+        if constexpr (BF) {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, so[r], 0, 0);
+          raw[r][2 * c] = __builtin_bit_cast(float, (unsigned)t[0]);
+          raw[r][2 * c + 1] = __builtin_bit_cast(float, (unsigned)t[1]);
+        } else {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, so[r], 0, 0);
+#pragma unroll
+          for (int vx = 0; vx < 4; vx++) raw[r][c * 4 + vx] = __builtin_bit_cast(float, (unsigned)t[vx]);
         }
       }
     }
-  } else {
-    const int so = MODE == 2 ? 2 : 1;
-    const int qz = MODE == 2 ? (ocls >> 2) & 1 : 0, qy = MODE == 2 ? (ocls >> 1) & 1 : 0, qx = MODE == 2 ? ocls & 1 : 0;
+  };
+  // maxima: as in the class form (the pairs together see every element; a quad's columns beyond the halo belong to the same
+  // tensor, so the tile scale is only more cautious and the exported maxima stay exact)
+  const bool export_max = !BF && p.amax_out != nullptr && nblk == 0;
+  float rmax0 = 0.f, rmax1 = 0.f, rmax2 = 0.f, rmax3 = 0.f;
+  auto publish_max = [&](const int parity, const int cc) {
+    if constexpr (BF) return;
+    float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < RT; i++)
+    for (int r = 0; r < FNR; r++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-        if (n >= p.N) continue;
-        const int si = cat_find(p.out, n);
-        float* base = cat_ptr(p.out, si);
-        if (base == nullptr) continue;
-        const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
-        const float bv = p.bias ? p.bias[n] : 0.f;
+      for (int c = 0; c < RW; c += 2) m = fmaxf(fmaxf(m, fabsf(raw[r][c])), fabsf(raw[r][c + 1]));
+    m = split_wave_max(m);
+    if (lane == 0) xmax[parity * 4 + wave] = m;
+    if (export_max) {
+      const int gc0 = cc * HKC + sh * 8;
+      const int sa = slice_of(gc0 < p.K ? gc0 : p.K - 1), sb = slice_of(gc0 + 7 < p.K ? gc0 + 7 : p.K - 1);
+      auto credit = [&](const int sl, const float mv) {
+        rmax0 = sl == 0 ? fmaxf(rmax0, mv) : rmax0;
+        rmax1 = sl == 1 ? fmaxf(rmax1, mv) : rmax1;
+        rmax2 = sl == 2 ? fmaxf(rmax2, mv) : rmax2;
+        rmax3 = sl == 3 ? fmaxf(rmax3, mv) : rmax3;
+      };
+      if (sa == sb) {
+        credit(sa, m);
+      } else {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const int vt = 2 * wave + j;
-          const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
-          if (oz < TZ && oy < TY)
-            st_act<BF>(base, boff + ((long long)(oz * so + qz) * p.TY_ + (oy * so + qy)) * p.TX_ + (ox * so + qx),
-                       split_act(acc[i][j][r] * out_mult + bv, p.act));
+        for (int c = 0; c < 8; c++) {
+          float mc = 0.f;
+#pragma unroll
+          for (int r = 0; r < FNR; r++)
+#pragma unroll
+            for (int vx = 0; vx < 4; vx++) mc = fmaxf(mc, fabsf(raw[r][c * 4 + vx]));
+          mc = split_wave_max(mc);
+          credit(slice_of(gc0 + c < p.K ? gc0 + c : p.K - 1), mc);
         }
       }
+    }
+  };
+  auto next_scale = [&](const int parity, const int s_run) {
+    if constexpr (BF) return 0;
+    const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
+    const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
+    return s_c < s_run ? s_c : s_run;
+  };
+  // voxel vx of a quad: x parity vx & 1 -> plane set, halo column 2 q - 1 + (vx >> 1); a 16-byte piece = this wave's 8 channels
+  auto split_and_write = [&](const float in_mult) {
+#pragma unroll
+    for (int r = 0; r < FNR; r++)
+#pragma unroll
+      for (int vx = 0; vx < 4; vx++) {
+        unsigned char* dst = Hs + (vx & 1) * G::PXB + sh * HPLANE + fwr[r] + (vx >> 1) * 16;
+        if constexpr (BF) {
+          u32x4 pc;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const unsigned a = __builtin_bit_cast(unsigned, raw[r][2 * (2 * k) + (vx >> 1)]);
+            const unsigned bq = __builtin_bit_cast(unsigned, raw[r][2 * (2 * k + 1) + (vx >> 1)]);
+            pc[k] = __builtin_amdgcn_perm(bq, a, (vx & 1) ? 0x07060302u : 0x05040100u);   // channels 2k, 2k + 1 at voxel vx
+          }
+          if ((fvox[r] >> vx) & 1) *reinterpret_cast<u32x4*>(dst) = pc;
+        } else {
+          h8 hi, lo;
+          split_piece(&raw[r][vx], 4, in_mult, hi, lo);
+          if ((fvox[r] >> vx) & 1) {
+            *reinterpret_cast<h8*>(dst) = hi;
+            *reinterpret_cast<h8*>(dst + 2 * HPLANE) = lo;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one voxel at a time: its pieces die before the next one's are built
+      }
+  };
+
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wimg) + (size_t)(p.nb_off + nblk) * p.blk_stride;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)p.blk_stride, 0x00020000);
+  auto dma_w = [&](const int woff, const int npieces, unsigned char* W) {
+#pragma unroll
+    for (int ii = 0; ii < (TPP * NP * RT + 3) / 4; ii++) {
+      const int i = wave + 4 * ii;
+      if (i < npieces) split_lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
+    }
+  };
+
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int vt = 2 * wave + j;
+    bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
   }
+  const int abase = lane * 16;
+
+  // ---- prologue
+  int pp = 0, cc_cur = 0;
+  auto pp_n_of = [&](const int pp_, const int cc_) { const int q = cc_ + 1 == cpc ? pp_ + 1 : pp_; return q > 3 ? 3 : q; };
+  int woff = 0, gph = 0;
+  dma_w(0, (TPP < 3 ? TPP : 3) * NP * RT, Ws);   // (the first pair has 3 taps)
+  load_raw(true, 0, 0);
+  publish_max(0, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int s_run = next_scale(0, kSplitScaleNone);
+  split_and_write(ldexpf(1.f, s_run));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int vc = 0; vc < NV; vc++) {
+    const int pz = pp >> 1, py = pp & 1;
+    const int T = pair_taps(pp), nph = (T + TPP - 1) / TPP;
+    const int T_n = pair_taps(pp_n_of(pp, cc_cur));
+    int cc_n = cc_cur + 1, pp_n = pp;
+    if (cc_n == cpc) cc_n = 0, pp_n = pp + 1;
+    for (int ph = 0; ph < nph; ph++, gph++) {
+      const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
+      const int ntap = T - TPP * ph < TPP ? T - TPP * ph : TPP;
+      const int wsize = ntap * NP * RT * 1024;
+      const bool last = ph + 1 == nph;
+      const int ntap_n = last ? (T_n < TPP ? T_n : TPP) : (T - TPP * (ph + 1) < TPP ? T - TPP * (ph + 1) : TPP);
+      if (!(last && vc + 1 == NV)) dma_w(woff + wsize, ntap_n * NP * RT, Ws + ((gph + 1) & 1) * G::WBUF);
+      __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
+      if (ph == 0) load_raw(vc + 1 < NV, pp_n, cc_n);
+#pragma unroll
+      for (int ix = 0; ix < TPP; ix++) {
+        if (ix < ntap) {
+          const int t = TPP * ph + ix, g = t / 3, xt = t - 3 * g;   // tap of the list: (iz, iy) = g, x tap: k = 1 | 0 | 2
+          const int iz = g >> py, iy = g & py;
+          const unsigned char* Hk = Hs + (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+          h8 fa[NP][RT], fb[NP][2];
+#pragma unroll
+          for (int part = 0; part < NP; part++) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + ((ix * NP + part) * RT + i) * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
+          }
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              if constexpr (BF) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
+                                                                   acc[i][j], 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[NP - 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[NP - 1][i], fb[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+              }
+            }
+        }
+      }
+      // (as in the class form: the chunk's last phase publishes the maxima of the next chunk's rows)
+      if (last && vc + 1 < NV) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_max((vc + 1) & 1, cc_n);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (ph == 0) {   // next phase's weights landed (older than the NRAW raw-row loads issued behind them)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      woff += wsize;
+    }
+    if (vc + 1 < NV) {
+      const int s_next = next_scale((vc + 1) & 1, s_run);
+      const bool turn = (((vc + 1) >> S2FLIP_SH) ^ (vc >> S2FLIP_SH)) & 1;
+      if (!BF && (turn || s_next != s_run)) {
+        const float flip = ldexpf(turn ? -1.f : 1.f, s_next - s_run);
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] *= flip;
+      }
+      s_run = s_next;
+      split_and_write(ldexpf(1.f, s_run));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    cc_cur = cc_n;
+    pp = pp_n;
+  }
+
+  if (export_max && lane == 0) {
+    unsigned* slot = p.amax_out + ((v / p.nblk) & 63);
+    if (rmax0 > 0.f) atomicMax(slot, __float_as_uint(rmax0));
+    if (rmax1 > 0.f) atomicMax(slot + 64, __float_as_uint(rmax1));
+    if (rmax2 > 0.f) atomicMax(slot + 128, __float_as_uint(rmax2));
+    if (rmax3 > 0.f) atomicMax(slot + 192, __float_as_uint(rmax3));
+  }
+  const float out_mult = ldexpf((!BF && (((NV - 1) >> S2FLIP_SH) & 1)) ? -1.f : 1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
+  s2_epilogue<RT, 1, BF>(p, acc, out_mult, wave, lane, b, nblk, 0, z0, y0, x0, TZ, TY, TX);
 }
 
 // ---- weight split + packing.  Image of one row block (MODE 1) / of one (class, row block) (MODE 2), in execution
@@ -557,16 +904,25 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     r /= p.RT;
     const int cc = r % p.cpc;
     const int nb = r / p.cpc;
-    int cls = 0;
-    while (cls < 7 && tg >= cls_taps_before(cls + 1)) cls++;
-    const int tl = tg - cls_taps_before(cls);                       // local tap = (iz * ny + iy) * nx + ix
-    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
-    const int nx = 1 + px, ny = 1 + py;
-    const int ix = tl % nx, iy = (tl / nx) % ny, iz = tl / (nx * ny);
-    const int tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + tap_k(px, ix);   // original (kz, ky, kx)
+    int cls = 0, tl, tap, vc;
+    if (p.mode == 3) {   // paired forward: `cls` = pair 2 pz + py, local tap = 3 (iz * ny + iy) + x tap (k = 1 | 0 | 2)
+      while (cls < 3 && tg >= pair_taps_before(cls + 1)) cls++;
+      tl = tg - pair_taps_before(cls);
+      const int pz = cls >> 1, py = cls & 1, g = tl / 3, xt = tl - 3 * g;
+      const int iz = g >> py, iy = g & py;
+      tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + (xt == 0 ? 1 : xt == 1 ? 0 : 2);
+      vc = cls * p.cpc + cc;
+    } else {
+      while (cls < 7 && tg >= cls_taps_before(cls + 1)) cls++;
+      tl = tg - cls_taps_before(cls);                       // local tap = (iz * ny + iy) * nx + ix
+      const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+      const int nx = 1 + px, ny = 1 + py;
+      const int ix = tl % nx, iy = (tl / nx) % ny, iz = tl / (nx * ny);
+      tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + tap_k(px, ix);   // original (kz, ky, kx)
+      // execution-order chunk index (sign alternation): MODE 1: class * cpc + cc; MODE 2: cc (one class per image)
+      vc = p.mode == 1 ? cls * p.cpc + cc : cc;
+    }
     const int n = p.n_off + nb * (32 * p.RT) + rt * 32 + row;
-    // execution-order chunk index (sign alternation): MODE 1: class * cpc + cc; MODE 2: cc (one class per image)
-    const int vc = p.mode == 1 ? cls * p.cpc + cc : cc;
     const float* w = nullptr;
     long long kstride = 27;
     if (p.kind == SR3D_PACK_FWD) {
@@ -602,7 +958,9 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     }
     // piece index inside the image
     long long piece;
-    if (p.mode == 1) {   // row block: classes one after the other, each [cc][local tap][part][rt]
+    if (p.mode == 3) {   // row block: pairs one after the other, each [cc][local tap][part][rt]
+      piece = (long long)nb * p.cpc * 27 + (long long)pair_taps_before(cls) * p.cpc + (long long)cc * pair_taps(cls) + tl;
+    } else if (p.mode == 1) {   // row block: classes one after the other, each [cc][local tap][part][rt]
       piece = (long long)nb * p.cpc * 27 + (long long)cls_taps_before(cls) * p.cpc + (long long)cc * cls_taps(cls) + tl;
     } else {             // the 8 class images one after the other, each [row block][cc][local tap]
       piece = (long long)cls_taps_before(cls) * p.cpc * p.nblk + ((long long)nb * p.cpc + cc) * cls_taps(cls) + tl;
@@ -641,10 +999,15 @@ int set_attrs() {
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_fwd_kernel<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FGeo<2, BF>::LDS));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_fwd_kernel<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FGeo<1, BF>::LDS));
   return SR3D_OK;
 }
 
 }  // namespace
+
+// forward: both x parities per load (pack order 3) when the rows can be fetched as quads; SR3D_HCONV_S2_CLASS_FWD=1 keeps the class form
+bool sr3d_hconv_s2_fwd_paired(int IX) { return IX % 4 == 0 && getenv("SR3D_HCONV_S2_CLASS_FWD") == nullptr; }
 
 // header (64 bytes) + region A (64-row blocks) + region B (one block of <= 32 rows); 27 taps per (row block, chunk)
 size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf) {
@@ -743,7 +1106,19 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
       }
     }
     const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
-    if (mode == 1)
+    if (mode == 1 && sr3d_hconv_s2_fwd_paired(p.IX)) {   // (the image was packed in pair order: sr3d_pack_weights asks the same question)
+      for (int i = 0; i < p.in.n; i++)
+        SR3D_CHECK((reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 7 : 15)) == 0, SR3D_E_ARG,
+                   "stride-2 forward: x_srcs[%d] must be %d-byte aligned (X %% 4 == 0: rows are fetched as quads)", i, bf ? 8 : 16);
+      constexpr size_t l2b = FGeo<2, true>::LDS, l1b = FGeo<1, true>::LDS, l2f = FGeo<2, false>::LDS, l1f = FGeo<1, false>::LDS;
+      if (bf) {
+        if (rt == 2) hipLaunchKernelGGL((hconv_s2_fwd_kernel<2, true>), grid, dim3(HNT), l2b, st, q);
+        else hipLaunchKernelGGL((hconv_s2_fwd_kernel<1, true>), grid, dim3(HNT), l1b, st, q);
+      } else {
+        if (rt == 2) hipLaunchKernelGGL((hconv_s2_fwd_kernel<2, false>), grid, dim3(HNT), l2f, st, q);
+        else hipLaunchKernelGGL((hconv_s2_fwd_kernel<1, false>), grid, dim3(HNT), l1f, st, q);
+      }
+    } else if (mode == 1)
       bf ? launch_rt<1, true>(rt, grid, st, q) : launch_rt<1, false>(rt, grid, st, q);
     else {
       // quad loads of the dY rows: IX % 4 == 0 and 16-byte (bf16: 8-byte) aligned tensors (then every channel row is)

@@ -810,7 +810,7 @@ int sr3d_pack_weights(const sr3d_conv_desc_t* d, int kind, const void* w_feat, c
     return sr3d_hconv_pack(kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                            (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream, unsh ? d->Cout / 8 : 0);
   if (use_hconv_s2(d, d->Cin, hconv_fwd_rows(d, kind)))
-    return sr3d_hconv_s2_pack(1, kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
+    return sr3d_hconv_s2_pack(sr3d_hconv_s2_fwd_paired(d->X) ? 3 : 1, kind, d->Cout, d->Cin, hconv_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
                               (const float*)w_gate, nullptr, nullptr, w_packed, is_bf(d), (hipStream_t)stream);
   if (use_wino(d))
     return sr3d_wino_pack(kind, d->Cout, d->Cin, wino_fwd_rows(d, kind), d->Cin, (const float*)w_feat,
