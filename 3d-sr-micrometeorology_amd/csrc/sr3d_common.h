@@ -147,6 +147,7 @@ struct SrHconvS2Params {
 };
 int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st);   // max |x| into *slot (sr3d_hconv.hip)
 size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf = false);
+bool sr3d_hconv_s2_bwd_paired(const SrHconvS2Params& p, bool bf);   // input gradient: pack order / launch mode 4 instead of 2
 bool sr3d_hconv_s2_fwd_paired(int IX);   // forward image in pair order (pack mode 3) / paired kernel: X % 4 == 0
 int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, const float* w1, const float* w2,
                        const int* rbeg, const int* cbeg, void* image, bool bf, hipStream_t st);

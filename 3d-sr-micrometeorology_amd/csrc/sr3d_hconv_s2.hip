@@ -866,6 +866,315 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
   s2_epilogue<RT, 1, BF>(p, acc, out_mult, wave, lane, b, nblk, 0, z0, y0, x0, TZ, TY, TX);
 }
 
+// ---- INPUT GRADIENT WITH BOTH X CLASSES PER WORKGROUP (round 4; quad-load conditions of the class form).  The eight output
+// classes of the class form each stage the SAME dY halo (8 launches slices x 12 quad loads per lane and 16 channels, for 1 .. 8
+// taps); here blockIdx.z = (qz, qy) and a workgroup computes dx at x = 2 i AND 2 i + 1 from one halo: per (kz, ky) of the pair
+// three x taps -- k = 1 -> even x from dy[i]; k = 0 -> odd x from dy[i + 1]; k = 2 -> odd x from dy[i] (the B fragment of the
+// first) -- into two accumulator sets: half the vector-memory instructions and half the L2 reads per MFMA, one phase (barrier,
+// weight DMA) per three taps, and the two classes leave as ONE 8-byte (bf16: 4-byte) store per lane instead of two 4-byte
+// stores at an 8-byte pitch from different workgroups.  128 accumulator registers: two workgroups per CU.
+template <int RT, bool BF>
+struct PGeo {
+  static constexpr int NP = BF ? 1 : 2;
+  static constexpr int WBUF = 3 * NP * RT * 1024;   // one phase: the three x taps of a (kz, ky)
+  static constexpr int HB = NP * 2 * HPLANE;
+  static constexpr size_t LDS = HB + 2 * (size_t)WBUF;
+};
+static_assert(2 * PGeo<2, false>::LDS <= 160 * 1024, "LDS budget of the paired input gradient");
+
+template <int RT, bool BF>
+__global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconvS2Params p) {
+  using G = PGeo<RT, BF>;
+  constexpr int NP = G::NP;
+  constexpr int ESZ = BF ? 2 : 4;
+  constexpr int QNR = 3, QPR = 9;
+  constexpr int NRAW = 4 * QNR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Hs = lds;
+  unsigned char* Ws = lds + G::HB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < HNT / 64);
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = v % p.nblk;
+  int blk = v / p.nblk;
+  const int tix = blk % p.ntx;
+  blk /= p.ntx;
+  const int tiy = blk % p.nty;
+  const int tiz = blk / p.nty;
+  const int b = blockIdx.y;
+  const int pq = (int)blockIdx.z;                 // 2 qz + qy
+  const int qz = pq >> 1, qy = pq & 1;
+  const int c0 = 4 * qz + 2 * qy;                 // the even-x class of the pair
+  const int TZ = p.cZ[c0], TY = p.cY[c0], TX0 = p.cX[c0], TX1 = p.cX[c0 + 1];
+  const int z0 = tiz * 2, y0 = tiy * 4, x0 = tix * 32;
+  if (z0 >= TZ || y0 >= TY || x0 >= TX0) return;  // (the grid is sized for the largest class)
+  const long long IZYX = (long long)p.IZ * p.IY * p.IX;
+  const int chan_bytes = (int)(IZYX * ESZ);
+
+  int sw = BF ? 0 : split_scale_exp(*p.absmax_w);
+  if (sw == kSplitScaleNone) sw = 0;
+  float* xmax = reinterpret_cast<float*>(Hs + HVOX * 16);
+
+  unsigned qoff[QNR];
+  int qwr[QNR], qmask[QNR];
+#pragma unroll
+  for (int r = 0; r < QNR; r++) {
+    const int t = r * 64 + lane;
+    const int row = t / QPR, q = t - row * QPR;
+    const int hz = row / UY, hy = row - hz * UY;
+    const int gz = z0 + hz, gy = y0 + hy, gx = x0 + 4 * q;
+    const bool task = t < UZ * UY * QPR;
+    const bool ok = task && (unsigned)gz < (unsigned)p.IZ && (unsigned)gy < (unsigned)p.IY && (unsigned)gx < (unsigned)p.IX;
+    qoff[r] = ok ? (unsigned)((gz * p.IY + gy) * p.IX + gx) * (unsigned)ESZ : 0xffffffffu;
+    qwr[r] = ((hz * HHY + hy) * HHX + 4 * q) * 16;
+    qmask[r] = !task ? 0 : (q == QPR - 1 ? 1 : 15);
+  }
+
+#define SR3D_SLICE_BASE(i) (reinterpret_cast<unsigned long long>(p.in.ptr[i]) + (unsigned long long)((long long)b * p.in.bstride[i]) * ESZ)
+  unsigned long long sb0 = SR3D_SLICE_BASE(0), sb1 = SR3D_SLICE_BASE(1), sb2 = SR3D_SLICE_BASE(2), sb3 = SR3D_SLICE_BASE(3);
+#undef SR3D_SLICE_BASE
+  int cb0 = p.in.cbeg[0], cb1 = p.in.cbeg[1], cb2 = p.in.cbeg[2], cb3 = p.in.cbeg[3];
+  split_pin_scalar(sb0), split_pin_scalar(sb1), split_pin_scalar(sb2), split_pin_scalar(sb3);
+  split_pin_scalar(cb0), split_pin_scalar(cb1), split_pin_scalar(cb2), split_pin_scalar(cb3);
+  unsigned long long dsb1 = sb1 - sb0, dsb2 = sb2 - sb1, dsb3 = sb3 - sb2;
+  int dcb1 = cb1 - cb0, dcb2 = cb2 - cb1, dcb3 = cb3 - cb2;
+  split_pin_scalar(dsb1), split_pin_scalar(dsb2), split_pin_scalar(dsb3), split_pin_scalar(dcb1), split_pin_scalar(dcb2), split_pin_scalar(dcb3);
+  auto chan_base = [&](const int gc) {
+    const long long m1 = -(long long)(gc >= cb1), m2 = -(long long)(gc >= cb2), m3 = -(long long)(gc >= cb3);
+    const unsigned long long base = sb0 + (dsb1 & (unsigned long long)m1) + (dsb2 & (unsigned long long)m2) + (dsb3 & (unsigned long long)m3);
+    const int cc0 = cb0 + (dcb1 & (int)m1) + (dcb2 & (int)m2) + (dcb3 & (int)m3);
+    return base + (unsigned long long)(unsigned)(gc - cc0) * (unsigned long long)(unsigned)chan_bytes;
+  };
+
+  const int NV = p.nchunks;
+  constexpr int RW = BF ? 8 : 16;    // fp32: [channel 0..3][voxel]; bf16: [channel][dword: voxels (0, 1) | (2, 3)]
+  float rawq[QNR][RW];
+  auto load_raw = [&](const bool live, const int cc) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int gc = cc * HKC + wave * 4 + c;   // wave-uniform
+      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < QNR; r++) {
+        if constexpr (BF) {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, qoff[r], 0, 0);
+          rawq[r][c * 2 + 0] = __builtin_bit_cast(float, (unsigned)t[0]);
+          rawq[r][c * 2 + 1] = __builtin_bit_cast(float, (unsigned)t[1]);
+        } else {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, qoff[r], 0, 0);
+#pragma unroll
+          for (int vx = 0; vx < 4; vx++) rawq[r][c * 4 + vx] = __builtin_bit_cast(float, (unsigned)t[vx]);
+        }
+      }
+    }
+  };
+  auto publish_max = [&](const int parity) {
+    if constexpr (BF) return;
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < QNR; r++)
+#pragma unroll
+      for (int c = 0; c < RW; c += 2) m = fmaxf(fmaxf(m, fabsf(rawq[r][c])), fabsf(rawq[r][c + 1]));
+    m = split_wave_max(m);
+    if (lane == 0) xmax[parity * 4 + wave] = m;
+  };
+  auto next_scale = [&](const int parity, const int s_run) {
+    if constexpr (BF) return 0;
+    const float m = fmaxf(fmaxf(xmax[parity * 4 + 0], xmax[parity * 4 + 1]), fmaxf(xmax[parity * 4 + 2], xmax[parity * 4 + 3]));
+    const int s_c = __builtin_amdgcn_readfirstlane(split_scale_exp(m));
+    return s_c < s_run ? s_c : s_run;
+  };
+  // channels 4 w .. 4 w + 3 = bytes 8 (w & 1) .. + 7 of the 16-byte piece of channel half w >> 1
+  auto split_and_write = [&](const float in_mult) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned char* H0 = Hs + (wave >> 1) * HPLANE + (wave & 1) * 8;
+#pragma unroll
+    for (int r = 0; r < QNR; r++)
+#pragma unroll
+      for (int vx = 0; vx < 4; vx++) {
+        if constexpr (BF) {
+          const unsigned sel = (vx & 1) ? 0x07060302u : 0x05040100u;
+          const unsigned a0 = __builtin_bit_cast(unsigned, rawq[r][0 * 2 + (vx >> 1)]), a1 = __builtin_bit_cast(unsigned, rawq[r][1 * 2 + (vx >> 1)]);
+          const unsigned a2 = __builtin_bit_cast(unsigned, rawq[r][2 * 2 + (vx >> 1)]), a3 = __builtin_bit_cast(unsigned, rawq[r][3 * 2 + (vx >> 1)]);
+          if ((qmask[r] >> vx) & 1)
+            *reinterpret_cast<u32x2*>(H0 + qwr[r] + vx * 16) = u32x2{__builtin_amdgcn_perm(a1, a0, sel), __builtin_amdgcn_perm(a3, a2, sel)};
+        } else {
+          unsigned h0, l0, h1, l1;
+          split_pair(rawq[r][0 * 4 + vx], rawq[r][1 * 4 + vx], in_mult, h0, l0);
+          split_pair(rawq[r][2 * 4 + vx], rawq[r][3 * 4 + vx], in_mult, h1, l1);
+          if ((qmask[r] >> vx) & 1) {
+            *reinterpret_cast<u32x2*>(H0 + qwr[r] + vx * 16) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(H0 + 2 * HPLANE + qwr[r] + vx * 16) = u32x2{l0, l1};
+          }
+        }
+      }
+  };
+
+  const int T = pair_taps(pq), nph = T / 3;      // phases of a chunk: the (kz, ky) of the pair
+  const long long blk_bytes = (long long)p.nchunks * T * NP * RT * 1024;
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wimg) + p.cls_off[pq] + (size_t)(p.nb_off + nblk) * blk_bytes;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)blk_bytes, 0x00020000);
+  auto dma_w = [&](const int woff, unsigned char* W) {
+#pragma unroll
+    for (int ii = 0; ii < (3 * NP * RT + 3) / 4; ii++) {
+      const int i = wave + 4 * ii;
+      if (i < 3 * NP * RT) split_lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
+    }
+  };
+
+  f32x16 acc[2][RT][2];   // [x class][row tile][voxel row]
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[c][i][j][r] = 0.f;
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int vt = 2 * wave + j;
+    bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
+  }
+  const int abase = lane * 16;
+  constexpr int WSIZE = 3 * NP * RT * 1024;
+
+  int woff = 0, gph = 0;
+  dma_w(0, Ws);
+  load_raw(true, 0);
+  publish_max(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int s_run = next_scale(0, kSplitScaleNone);
+  split_and_write(ldexpf(1.f, s_run));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int vc = 0; vc < NV; vc++) {
+    for (int ph = 0; ph < nph; ph++, gph++) {
+      const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
+      const bool last = ph + 1 == nph;
+      if (!(last && vc + 1 == NV)) dma_w(woff + WSIZE, Ws + ((gph + 1) & 1) * G::WBUF);
+      __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
+      if (ph == 0) load_raw(vc + 1 < NV, vc + 1);
+      const int iz = ph >> qy, iy = ph & qy;   // ph = iz * (1 + qy) + iy
+      const unsigned char* Hk = Hs + ((tap_h(2, qz, iz) * HHY + tap_h(2, qy, iy)) * HHX) * 16;
+      // x taps: 0: k = 1, even x, dy[i]; 1: k = 0, odd x, dy[i + 1]; 2: k = 2, odd x, dy[i]
+#pragma unroll
+      for (int hx = 0; hx < 2; hx++) {
+        h8 fb[NP][2];
+#pragma unroll
+        for (int part = 0; part < NP; part++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j] + hx * 16);
+#pragma unroll
+        for (int xt = 0; xt < 3; xt++) {
+          if ((xt == 1) != (hx == 1)) continue;
+          h8 fa[NP][RT];
+#pragma unroll
+          for (int part = 0; part < NP; part++)
+#pragma unroll
+            for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + ((xt * NP + part) * RT + i) * 1024);
+          const int cx = xt == 0 ? 0 : 1;
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              if constexpr (BF) {
+                acc[cx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
+                                                                       acc[cx][i][j], 0, 0, 0);
+              } else {
+                acc[cx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[NP - 1][j], acc[cx][i][j], 0, 0, 0);
+                acc[cx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[NP - 1][i], fb[0][j], acc[cx][i][j], 0, 0, 0);
+                acc[cx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[cx][i][j], 0, 0, 0);
+              }
+            }
+        }
+      }
+      if (last && vc + 1 < NV) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_max((vc + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (ph == 0) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      woff += WSIZE;
+    }
+    if (vc + 1 < NV) {
+      const int s_next = next_scale((vc + 1) & 1, s_run);
+      const bool turn = (((vc + 1) >> S2FLIP_SH) ^ (vc >> S2FLIP_SH)) & 1;
+      if (!BF && (turn || s_next != s_run)) {
+        const float flip = ldexpf(turn ? -1.f : 1.f, s_next - s_run);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int r = 0; r < 16; r++) acc[c][i][j][r] *= flip;
+      }
+      s_run = s_next;
+      split_and_write(ldexpf(1.f, s_run));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue: dx[2 oz + qz][2 oy + qy][2 ox], [.. + 1] of GEMM row n
+  const float out_mult = ldexpf((!BF && (((NV - 1) >> S2FLIP_SH) & 1)) ? -1.f : 1.f, -((s_run == kSplitScaleNone ? 0 : s_run) + sw));
+  const int ox = x0 + (lane & 31);
+  if (ox >= TX0) return;
+  const bool has1 = ox < TX1;
+  const int rblock = p.n_off + (p.nb_off + nblk) * 64;
+  const long long TZYX = (long long)p.TZ_ * p.TY_ * p.TX_;
+  const bool row_even = (p.TX_ & 1) == 0;          // then every (2 ox) element of a row is 8-byte (bf16: 4-byte) aligned with its tensor
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = rblock + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+      if (n >= p.N) continue;
+      const int si = cat_find(p.out, n);
+      float* base = cat_ptr(p.out, si);
+      if (base == nullptr) continue;
+      const long long boff = (long long)b * cat_bstride(p.out, si) + (long long)(n - cat_cbeg(p.out, si)) * TZYX;   // elements
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const bool vec = has1 && row_even && ((reinterpret_cast<uintptr_t>(base) & (BF ? 3 : 7)) == 0) && ((boff & 1) == 0);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int vt = 2 * wave + j;
+        const int oz = z0 + (vt >> 2), oy = y0 + (vt & 3);
+        if (oz >= TZ || oy >= TY) continue;
+        const long long o = boff + ((long long)(oz * 2 + qz) * p.TY_ + (oy * 2 + qy)) * p.TX_ + 2 * ox;
+        const float v0 = split_act(acc[0][i][j][r] * out_mult + bv, p.act), v1 = split_act(acc[1][i][j][r] * out_mult + bv, p.act);
+        if (vec) {
+          if constexpr (BF) {
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v0) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v1) << 16);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(base) + o) = pk;
+          } else {
+            *reinterpret_cast<float2*>(base + o) = float2{v0, v1};
+          }
+        } else {
+          st_act<BF>(base, o, v0);
+          if (has1) st_act<BF>(base, o + 1, v1);
+        }
+      }
+    }
+}
+
 // ---- weight split + packing.  Image of one row block (MODE 1) / of one (class, row block) (MODE 2), in execution
 // order: [class][chunk][phase (iz, iy)][ix][part][row tile][channel half][32 rows][8 ch] fp16
 struct S2PackParams {
@@ -905,13 +1214,13 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     const int cc = r % p.cpc;
     const int nb = r / p.cpc;
     int cls = 0, tl, tap, vc;
-    if (p.mode == 3) {   // paired forward: `cls` = pair 2 pz + py, local tap = 3 (iz * ny + iy) + x tap (k = 1 | 0 | 2)
+    if (p.mode >= 3) {   // paired forward (3) / paired input gradient (4): `cls` = pair 2 pz + py, local tap = 3 (iz * ny + iy) + x tap (k = 1 | 0 | 2)
       while (cls < 3 && tg >= pair_taps_before(cls + 1)) cls++;
       tl = tg - pair_taps_before(cls);
       const int pz = cls >> 1, py = cls & 1, g = tl / 3, xt = tl - 3 * g;
       const int iz = g >> py, iy = g & py;
       tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + (xt == 0 ? 1 : xt == 1 ? 0 : 2);
-      vc = cls * p.cpc + cc;
+      vc = p.mode == 3 ? cls * p.cpc + cc : cc;
     } else {
       while (cls < 7 && tg >= cls_taps_before(cls + 1)) cls++;
       tl = tg - cls_taps_before(cls);                       // local tap = (iz * ny + iy) * nx + ix
@@ -958,7 +1267,9 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     }
     // piece index inside the image
     long long piece;
-    if (p.mode == 3) {   // row block: pairs one after the other, each [cc][local tap][part][rt]
+    if (p.mode == 4) {   // the 4 pair images one after the other, each [row block][cc][local tap]
+      piece = (long long)pair_taps_before(cls) * p.cpc * p.nblk + ((long long)nb * p.cpc + cc) * pair_taps(cls) + tl;
+    } else if (p.mode == 3) {   // row block: pairs one after the other, each [cc][local tap][part][rt]
       piece = (long long)nb * p.cpc * 27 + (long long)pair_taps_before(cls) * p.cpc + (long long)cc * pair_taps(cls) + tl;
     } else if (p.mode == 1) {   // row block: classes one after the other, each [cc][local tap][part][rt]
       piece = (long long)nb * p.cpc * 27 + (long long)cls_taps_before(cls) * p.cpc + (long long)cc * cls_taps(cls) + tl;
@@ -999,6 +1310,8 @@ int set_attrs() {
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<2, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_kernel<1, 2, BF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_bwd_pair_kernel<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PGeo<2, BF>::LDS));
+  SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_bwd_pair_kernel<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PGeo<1, BF>::LDS));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_fwd_kernel<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FGeo<2, BF>::LDS));
   SR3D_HIP(hipFuncSetAttribute((const void*)hconv_s2_fwd_kernel<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FGeo<1, BF>::LDS));
   return SR3D_OK;
@@ -1008,6 +1321,14 @@ int set_attrs() {
 
 // forward: both x parities per load (pack order 3) when the rows can be fetched as quads; SR3D_HCONV_S2_CLASS_FWD=1 keeps the class form
 bool sr3d_hconv_s2_fwd_paired(int IX) { return IX % 4 == 0 && getenv("SR3D_HCONV_S2_CLASS_FWD") == nullptr; }
+
+// input gradient: both x classes per workgroup (pack order 4, launch mode 4) when the dY rows can be fetched as quads;
+// SR3D_HCONV_S2_CLASS_BWD=1 keeps the class form
+bool sr3d_hconv_s2_bwd_paired(const SrHconvS2Params& p, bool bf) {
+  bool quad = p.IX % 4 == 0 && getenv("SR3D_HCONV_NO_PAIR") == nullptr && getenv("SR3D_HCONV_S2_CLASS_BWD") == nullptr;
+  for (int i = 0; i < p.in.n; i++) quad = quad && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 7 : 15)) == 0;
+  return quad;
+}
 
 // header (64 bytes) + region A (64-row blocks) + region B (one block of <= 32 rows); 27 taps per (row block, chunk)
 size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf) {
@@ -1104,8 +1425,21 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
         q.cls_off[c] = (long long)((size_t)cls_taps_before(c) * cpc * nb * piece);
         q.cls_blk[c] = (long long)(cpc * cls_taps(c) * piece);
       }
+      if (mode == 4)
+        for (int c = 0; c < 4; c++) q.cls_off[c] = (long long)((size_t)pair_taps_before(c) * cpc * nb * piece);
     }
-    const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : 1);
+    const dim3 grid((unsigned)(nsp * nb), B, mode == 2 ? 8 : mode == 4 ? 4 : 1);
+    if (mode == 4) {
+      constexpr size_t l2b = PGeo<2, true>::LDS, l1b = PGeo<1, true>::LDS, l2f = PGeo<2, false>::LDS, l1f = PGeo<1, false>::LDS;
+      if (bf) {
+        if (rt == 2) hipLaunchKernelGGL((hconv_s2_bwd_pair_kernel<2, true>), grid, dim3(HNT), l2b, st, q);
+        else hipLaunchKernelGGL((hconv_s2_bwd_pair_kernel<1, true>), grid, dim3(HNT), l1b, st, q);
+      } else {
+        if (rt == 2) hipLaunchKernelGGL((hconv_s2_bwd_pair_kernel<2, false>), grid, dim3(HNT), l2f, st, q);
+        else hipLaunchKernelGGL((hconv_s2_bwd_pair_kernel<1, false>), grid, dim3(HNT), l1f, st, q);
+      }
+      continue;
+    }
     if (mode == 1 && sr3d_hconv_s2_fwd_paired(p.IX)) {   // (the image was packed in pair order: sr3d_pack_weights asks the same question)
       for (int i = 0; i < p.in.n; i++)
         SR3D_CHECK((reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 7 : 15)) == 0, SR3D_E_ARG,

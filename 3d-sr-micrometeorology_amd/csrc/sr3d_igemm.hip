@@ -1125,8 +1125,9 @@ static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
     q.Z = d->Z, q.Y = d->Y, q.X = d->X;
     q.TZ_ = d->Z, q.TY_ = d->Y, q.TX_ = d->X;
     q.epi = SR3D_EPI_PLAIN, q.act = SR3D_ACT_NONE;
-    if (int rc = sr3d_hconv_s2_pack(2, pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
-    return sr3d_hconv_s2_launch(2, q, image, d->B, is_bf(d), st);
+    const int s2mode = sr3d_hconv_s2_bwd_paired(q, is_bf(d)) ? 4 : 2;   // 4: both x classes per workgroup (quad loads possible)
+    if (int rc = sr3d_hconv_s2_pack(s2mode, pk.kind, d->Cout, d->Cin, rows, K, pk.w1, pk.w2, pk.rbeg, pk.cbeg, image, is_bf(d), st)) return rc;
+    return sr3d_hconv_s2_launch(s2mode, q, image, d->B, is_bf(d), st);
   }
   using C = IgemmCfg<1, 0, 1, 2, 4, 4, kKC>;
   // the 8 output-parity classes: packed one after the other, then ONE launch with blockIdx.z = class
