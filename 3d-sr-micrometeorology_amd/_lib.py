@@ -60,6 +60,7 @@ SYMBOLS = {
     "sr3d_bias_grad_workspace_bytes": (_SZ, [_I, _I, _LL]),
     "sr3d_bias_grad": (_I, [_P, _I, _I, _LL, _P, _P, _I, _P]),
     "sr3d_gated_act_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _P, _P]),
+    "sr3d_gated_act_bwd_sum": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P, _P]),
     "sr3d_lrelu_bwd": (_I, [_P, _P, _P, _LL, _I, _P, _P]),
     "sr3d_unshuffle_lrelu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sr3d_upsample_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -35,8 +35,10 @@ __device__ __forceinline__ void export_absmax(float m, unsigned* slots) {
 // d_feat = dy * s * act'(f);  d_gate = dy * f * s * (1 - s)        (T: storage type, float or bf16raw; fp32 arithmetic)
 // FROM_Y: the second operand is the layer's OUTPUT y = s * act(f) instead of act(f) (SR3D_ACT_FROM_Y): s > 0, so y has
 // the sign of act(f) -- the same act' -- and f * s = y: d_gate = dy * y * (1 - s).  The forward then stores no act(f) at all.
+// dy2 (may be null): a SECOND incoming gradient of the same output -- the skip connection's -- added on the fly (in fp32),
+// instead of a separate elementwise add of the two gradient tensors in front of this pass (3 tensor passes less).
 template <typename T, bool FROM_Y>
-__global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ f,
+__global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ f,
                                                                  const T* __restrict__ s, T* __restrict__ df,
                                                                  T* __restrict__ dg, long long n, int act, unsigned* amax) {
   float m1 = 0.f, m2 = 0.f;
@@ -44,7 +46,9 @@ __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __rest
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long long i = i0; i < n4; i += stride) {
-    const f32x4 a = ActIo<T>::ld4(dy + 4 * i), ff = ActIo<T>::ld4(f + 4 * i), ss = ActIo<T>::ld4(s + 4 * i);
+    f32x4 a = ActIo<T>::ld4(dy + 4 * i);
+    const f32x4 ff = ActIo<T>::ld4(f + 4 * i), ss = ActIo<T>::ld4(s + 4 * i);
+    if (dy2 != nullptr) a += ActIo<T>::ld4(dy2 + 4 * i);   // (kernel argument: uniform)
     f32x4 o1, o2;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void gated_act_bwd_kernel(const T* __rest
     ActIo<T>::st4(dg + 4 * i, o2);
   }
   for (long long i = n4 * 4 + i0; i < n; i += stride) {
-    const float a = ActIo<T>::ld(dy + i), ff = ActIo<T>::ld(f + i), ss = ActIo<T>::ld(s + i);
+    const float a = ActIo<T>::ld(dy + i) + (dy2 != nullptr ? ActIo<T>::ld(dy2 + i) : 0.f), ff = ActIo<T>::ld(f + i), ss = ActIo<T>::ld(s + i);
     const float v1 = a * ss * act_slope(ff, act), v2 = FROM_Y ? a * ff * (1.f - ss) : a * ff * (ss * (1.f - ss));
     m1 = fmaxf(m1, fabsf(v1)), m2 = fmaxf(m2, fabsf(v2));
     ActIo<T>::st(df + i, v1);
@@ -412,32 +416,38 @@ extern "C" {
 
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
                        long long n, int act, int dtype, void* absmax_out, void* stream) {
+  return sr3d_gated_act_bwd_sum(dy, nullptr, save_f, save_s, d_feat, d_gate, n, act, dtype, absmax_out, stream);
+}
+
+int sr3d_gated_act_bwd_sum(const void* dy, const void* dy2, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
+                           long long n, int act, int dtype, void* absmax_out, void* stream) {
   SR3D_DTYPE_CHECK(dtype, "gated_act_bwd");
   SR3D_CHECK(dy && save_f && save_s && d_feat && d_gate && n > 0, SR3D_E_ARG, "gated_act_bwd: bad argument");
   const bool from_y = (act & SR3D_ACT_FROM_Y) != 0;
   act &= ~SR3D_ACT_FROM_Y;
   SR3D_CHECK(act >= 0 && act <= 2, SR3D_E_ARG, "gated_act_bwd: unknown activation %d", act);
   SR3D_ALIGN_CHECK(dy, "gated_act_bwd");
+  if (dy2 != nullptr) SR3D_ALIGN_CHECK(dy2, "gated_act_bwd");
   SR3D_ALIGN_CHECK(save_f, "gated_act_bwd");
   SR3D_ALIGN_CHECK(save_s, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_feat, "gated_act_bwd");
   SR3D_ALIGN_CHECK(d_gate, "gated_act_bwd");
   const double esz = dtype == SR3D_DTYPE_BF16 ? 2.0 : 4.0;
-  SrProfScope prof(SR3D_PROF_ACT_BWD, 5.0 * esz * (double)n, (hipStream_t)stream);   // 3 reads + 2 writes
+  SrProfScope prof(SR3D_PROF_ACT_BWD, (dy2 ? 6.0 : 5.0) * esz * (double)n, (hipStream_t)stream);   // 3 (4) reads + 2 writes
   const dim3 grid(blocks_for(n, 4)), block(kThreads);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SR3D_DTYPE_BF16) {
-    const bf16raw *a = (const bf16raw*)dy, *f = (const bf16raw*)save_f, *sg = (const bf16raw*)save_s;
+    const bf16raw *a = (const bf16raw*)dy, *a2 = (const bf16raw*)dy2, *f = (const bf16raw*)save_f, *sg = (const bf16raw*)save_s;
     if (from_y)
-      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, true>), grid, block, 0, st, a, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
+      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, true>), grid, block, 0, st, a, a2, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
     else
-      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, false>), grid, block, 0, st, a, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
+      hipLaunchKernelGGL((gated_act_bwd_kernel<bf16raw, false>), grid, block, 0, st, a, a2, f, sg, (bf16raw*)d_feat, (bf16raw*)d_gate, n, act, (unsigned*)nullptr);
   } else {
-    const float *a = (const float*)dy, *f = (const float*)save_f, *sg = (const float*)save_s;
+    const float *a = (const float*)dy, *a2 = (const float*)dy2, *f = (const float*)save_f, *sg = (const float*)save_s;
     if (from_y)
-      hipLaunchKernelGGL((gated_act_bwd_kernel<float, true>), grid, block, 0, st, a, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
+      hipLaunchKernelGGL((gated_act_bwd_kernel<float, true>), grid, block, 0, st, a, a2, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
     else
-      hipLaunchKernelGGL((gated_act_bwd_kernel<float, false>), grid, block, 0, st, a, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
+      hipLaunchKernelGGL((gated_act_bwd_kernel<float, false>), grid, block, 0, st, a, a2, f, sg, (float*)d_feat, (float*)d_gate, n, act, (unsigned*)absmax_out);
   }
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;

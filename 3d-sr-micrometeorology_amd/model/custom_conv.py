@@ -56,9 +56,9 @@ class GatedConv3d(nn.Module):
             if isinstance(m, nn.Conv3d):
                 nn.init.kaiming_normal_(m.weight)
 
-    def gated_forward(self, srcs, act: typing.Optional[str]) -> torch.Tensor:
+    def gated_forward(self, srcs, act: typing.Optional[str], dual: bool = False):
         return ops.gated_conv3d_act(srcs, self.conv3d.weight, self.mask_conv3d.weight, self.conv3d.bias,
-                                    self.mask_conv3d.bias, act=act, stride=self.stride)
+                                    self.mask_conv3d.bias, act=act, stride=self.stride, dual=dual)
 
 
 class GatedConv3dWithSeparatedBias(GatedConv3d):
@@ -88,14 +88,18 @@ class MyConvWithAct2(nn.Module):
         else:
             raise NotImplementedError(f"{conv_mode} is not supported.")
 
-    def forward(self, input: TensorOrList, defer_act_bwd: bool = False) -> torch.Tensor:
+    def forward(self, input: TensorOrList, defer_act_bwd: bool = False, dual: bool = False):
         """``defer_act_bwd`` (engine extension, plain LeakyReLU layers): the caller guarantees that the output feeds exactly one
-        engine convolution, whose input-gradient kernel then applies this layer's activation backward (ops.Conv3dAct)"""
+        engine convolution, whose input-gradient kernel then applies this layer's activation backward (ops.Conv3dAct).
+        ``dual`` (engine extension): return ``(y, y)`` -- two handles of one tensor for an output with two consumers (the
+        U-Net's skip tensors); a gated layer then adds the two incoming gradients inside its activation backward
+        (ops.GatedConv3dAct), any other layer returns the same tensor twice and autograd adds as usual."""
         srcs = _as_list(input)
         if self.conv_mode is None:
-            return ops.conv3d_act(srcs, self.conv.weight, self.conv.bias, act=self._act_name, stride=self.stride,
-                                  defer_act_bwd=defer_act_bwd)
-        return self.conv.gated_forward(srcs, self._act_name)
+            y = ops.conv3d_act(srcs, self.conv.weight, self.conv.bias, act=self._act_name, stride=self.stride,
+                               defer_act_bwd=defer_act_bwd)
+            return (y, y) if dual else y
+        return self.conv.gated_forward(srcs, self._act_name, dual=dual)
 
 
 class PartialConv3d(nn.Conv3d):

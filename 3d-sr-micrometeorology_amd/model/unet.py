@@ -30,10 +30,11 @@ class DownBlock(nn.Module):
                                          conv_mode=conv_mode, act=nn.ReLU()))
         self.convs = nn.Sequential(*layers)
 
-    def forward(self, x) -> torch.Tensor:
+    def forward(self, x, dual: bool = False):
+        """``dual``: the block's output as two handles (for the next block / for the skip connection; MyConvWithAct2.forward)"""
         y = x
-        for layer in self.convs:
-            y = layer(y)
+        for i, layer in enumerate(self.convs):
+            y = layer(y, dual=dual and i + 1 == len(self.convs))
         return y
 
 
@@ -140,22 +141,26 @@ class UNetSR(nn.Module):
         if self.act_dtype != torch.float32:
             x0, b, b1, b2, b3 = (t.to(self.act_dtype) for t in (x0, b, b1, b2, b3))
             b4 = b4.to(self.act_dtype) if b4 is not None else None
-        f0 = self.conv0([x0])
-        f1 = self.down1([f0, b])
-        f2 = self.down2([f1, b1])
-        f3 = self.down3([f2, b2])
+        # f0 .. f3 have two consumers each, the next block and the skip connection: two handles of one tensor, so that the
+        # producing gated layer adds the two gradients inside its activation backward (no elementwise add pass in between)
+        dual = ops.FUSE_SKIP_GRAD_ADD
+        f0, f0s = self.conv0([x0], dual=True) if dual else (self.conv0([x0]),) * 2
+        f1, f1s = self.down1([f0, b], dual=True) if dual else (self.down1([f0, b]),) * 2
+        f2, f2s = self.down2([f1, b1], dual=True) if dual else (self.down2([f1, b1]),) * 2
+        has4 = not (self.down4 is None and self.up4 is None)
+        f3, f3s = self.down3([f2, b2], dual=True) if (dual and has4) else (self.down3([f2, b2]),) * 2
 
-        if self.down4 is None and self.up4 is None:
+        if not has4:
             y = self._latent([f3, b3])
         else:
             f4 = self.down4([f3, b3])
             y = self._latent([f4, b4])
-            y = self.up4([y, b4], [f3, b3], defer_act_bwd=True)
+            y = self.up4([y, b4], [f3s, b3], defer_act_bwd=True)
         # (every LeakyReLU output below has ONE consumer, an engine convolution: its input-gradient epilogue applies the
         #  activation backward -- SURVEY K9 -- where the kernel has that epilogue; ops.Conv3dAct falls back otherwise)
-        y = self.up3([y, b3], [f2, b2], defer_act_bwd=True)
-        y = self.up2([y, b2], [f1, b1], defer_act_bwd=True)
-        y = self.up1([y, b1], [f0, b], defer_act_bwd=True)
+        y = self.up3([y, b3], [f2s, b2], defer_act_bwd=True)
+        y = self.up2([y, b2], [f1s, b1], defer_act_bwd=True)
+        y = self.up1([y, b1], [f0s, b], defer_act_bwd=True)
         w, bias = self.last.weight, self.last.bias
         # (bf16 storage: the prediction leaves `last` as fp32, the accumulator's value -- not rounded to bf16 and cast back)
         return ops.conv3d_act([y, x0], w, bias, act=None, stride=1, out_fp32=self.act_dtype != torch.float32)

@@ -131,6 +131,9 @@ def _bwd_weight(desc: L.ConvDesc, srcs, dys, x_amax=None, dy_amax=None) -> torch
 # activation backward of LeakyReLU layers fused into their consumer's input-gradient epilogue where the model asks
 # for it (`defer_act_bwd`) and the kernel has the epilogue; False keeps the separate lrelu_bwd pass (tests: A/B, bit-equality)
 FUSE_ACT_BWD = os.environ.get("SR3D_FUSE_ACT_BWD", "1") != "0"
+# the two gradients of a skip tensor (from the next block and from the skip connection) added inside the producing gated layer's
+# activation backward (sr3d_gated_act_bwd_sum) instead of by autograd in an elementwise pass of its own; False: autograd adds
+FUSE_SKIP_GRAD_ADD = os.environ.get("SR3D_FUSE_SKIP_GRAD_ADD", "1") != "0"
 
 
 class _ActBox:
@@ -266,7 +269,10 @@ class GatedConv3dAct(torch.autograd.Function):
     (reference custom_conv.py:119-123, 237-306)."""
 
     @staticmethod
-    def forward(ctx, w_feat, w_gate, b_feat, b_gate, act: Optional[str], stride: int, *srcs):
+    def forward(ctx, w_feat, w_gate, b_feat, b_gate, act: Optional[str], stride: int, dual: bool, *srcs):
+        """``dual``: return the output TWICE (the same storage): for an output with two consumers -- the next block and the
+        U-Net's skip connection -- backward then receives the two gradients separately and adds them inside
+        ``sr3d_gated_act_bwd_sum`` instead of autograd adding them in an elementwise pass of its own"""
         srcs = [s.contiguous() for s in srcs]
         B, cin, (Z, Y, X) = _check_srcs(srcs)
         cout = int(w_feat.shape[0])
@@ -296,36 +302,46 @@ class GatedConv3dAct(torch.autograd.Function):
             KINK_LOG.append((y > 0).cpu())       # (the sign of act(feat): sigmoid > 0)
         ctx.desc, ctx.act, ctx.nsrc, ctx.has_bf = desc, act, len(srcs), b_feat is not None
         ctx.save_for_backward(w_feat, w_gate, y if need_bwd else None, ss, *srcs)
-        return y
+        if not dual:
+            return y
+        ctx.set_materialize_grads(False)   # (an unused alias brings None, not a tensor of zeros)
+        return y, y.detach()
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         w_feat, w_gate, y, ss, *srcs = ctx.saved_tensors
         desc = ctx.desc
         dt = L.torch_dtype(desc)
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:                      # (neither output reached the loss)
+            return (None,) * (7 + ctx.nsrc)
         dy = dy.to(dt).contiguous()
+        dy2 = dy2.to(dt).contiguous() if dy2 is not None else None
         d_feat, d_gate = torch.empty_like(dy), torch.empty_like(dy)
         want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dy_amax = _amax_slots(2, dy) if (want_w and dt == torch.float32) else None
-        L.check(L.lib.sr3d_gated_act_bwd(L.dev_ptr(dy, "dy", dt), L.dev_ptr(y, "y", dt), L.dev_ptr(ss, "save_s", dt),
-                                         L.dev_ptr(d_feat, "d_feat", dt), L.dev_ptr(d_gate, "d_gate", dt), dy.numel(),
-                                         L.ACT_CODE[ctx.act] | L.ACT_FROM_Y, desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()),
-                "sr3d_gated_act_bwd")
-        needs = ctx.needs_input_grad[6:6 + ctx.nsrc]
+        L.check(L.lib.sr3d_gated_act_bwd_sum(L.dev_ptr(dy, "dy", dt), L.dev_ptr(dy2, "dy2", dt),
+                                             L.dev_ptr(y, "y", dt), L.dev_ptr(ss, "save_s", dt),
+                                             L.dev_ptr(d_feat, "d_feat", dt), L.dev_ptr(d_gate, "d_gate", dt), dy.numel(),
+                                             L.ACT_CODE[ctx.act] | L.ACT_FROM_Y, desc.dtype, _raw_ptr(dy_amax), L.stream_ptr()),
+                "sr3d_gated_act_bwd_sum")
+        needs = ctx.needs_input_grad[7:7 + ctx.nsrc]
         dxs, dw, (dbf, dbg) = _grads_two_streams(
             desc, srcs, needs, [d_feat, d_gate], w_feat, w_gate, want_w,
             [d_feat if (ctx.has_bf and ctx.needs_input_grad[2]) else None, d_gate if ctx.needs_input_grad[3] else None],
             ctx.x_amax, dy_amax)
         dwf, dwg = (dw[:desc.Cout], dw[desc.Cout:]) if dw is not None else (None, None)
-        return (dwf, dwg, dbf, dbg, None, None, *dxs)
+        return (dwf, dwg, dbf, dbg, None, None, None, *dxs)
 
 
 def conv3d_act(srcs, weight, bias=None, act=None, stride=1, unshuffle=False, defer_act_bwd=False, out_fp32=False):
     return Conv3dAct.apply(weight, bias, act, stride, unshuffle, defer_act_bwd, out_fp32, *srcs)
 
 
-def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):
-    return GatedConv3dAct.apply(w_feat, w_gate, b_feat, b_gate, act, stride, *srcs)
+def gated_conv3d_act(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1, dual=False):
+    """``dual=True`` returns (y, y again): see GatedConv3dAct.forward"""
+    return GatedConv3dAct.apply(w_feat, w_gate, b_feat, b_gate, act, stride, dual, *srcs)
 
 
 # ---------------------------------------------------------------- PartialConv3d pieces

@@ -162,6 +162,11 @@ int sr3d_bias_grad(const void* dy, int B, int C, long long voxels, void* db, voi
  * forward pass need not store act(feat) at all (sr3d_gated_conv3d_fwd with save_f = NULL, save_s given) */
 int sr3d_gated_act_bwd(const void* dy, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
                        long long n, int act, int dtype, void* absmax_out /* [2][64]: d_feat, d_gate */, void* stream);
+/* the same with dy + dy2 as the incoming gradient (dy2 may be NULL): a gated output that feeds TWO consumers -- the next block and the
+ * U-Net's skip connection (unet.py:262-283: f0..f3) -- receives two gradient tensors, which autograd would add in a pass of its own
+ * (AccumulateGrad / the engine's sum of a node's incoming gradients) before this one; the sum is formed in fp32 */
+int sr3d_gated_act_bwd_sum(const void* dy, const void* dy2, const void* save_f, const void* save_s, void* d_feat, void* d_gate,
+                           long long n, int act, int dtype, void* absmax_out /* [2][64] */, void* stream);
 /* dpre = dy * (y > 0 ? 1 : 0.01)        (autograd of nn.LeakyReLU, y = post-activation) */
 int sr3d_lrelu_bwd(const void* dy, const void* y, void* dpre, long long n, int dtype, void* absmax_out, void* stream);
 /* dpre(B, 8C, Z, Y, X) = shuffle_voxels(dy * lrelu'(y)) for y, dy of shape (B, C, 2Z, 2Y, 2X)

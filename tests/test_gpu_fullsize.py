@@ -404,11 +404,12 @@ def test_whole_model_step_at_baseline_size_layer_by_layer_vs_oracle(eng, monkeyp
                       "out": out, "deferred": getattr(out, "_sr3d_act_box", None) is not None})
         return out
 
-    def rec_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1):
-        out = orig_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=act, stride=stride)
+    def rec_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=None, stride=1, dual=False):
+        out = orig_gated(srcs, w_feat, w_gate, b_feat, b_gate, act=act, stride=stride, dual=dual)
+        # (dual: the skip tensors leave as two handles of one storage; the first is the layer's output for the checks below)
         calls.append({"kind": "gated", "name": names[id(w_feat)].rsplit(".", 1)[0], "srcs": [t.detach() for t in srcs],
                       "w": w_feat, "w_gate": w_gate, "b_feat": b_feat, "bias": b_gate, "act": act, "stride": stride,
-                      "unshuffle": False, "out": out})
+                      "unshuffle": False, "out": out[0] if dual else out})
         return out
 
     monkeypatch.setattr(eng.ops, "conv3d_act", rec_plain)

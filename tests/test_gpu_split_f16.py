@@ -351,3 +351,38 @@ def test_fused_activation_backward_equals_the_separate_pass_bit_for_bit(eng, mon
     assert res[False][1] == (11, 4) and res[True][1] == (0, 0), (res[True][1], res[False][1])
     for k, g in res[True][0].items():
         assert torch.equal(g, res[False][0][k]), k
+
+
+def test_skip_gradient_sum_inside_the_gated_backward_equals_autograds_add_bit_for_bit(eng, monkeypatch):
+    """The skip tensors f0..f3 (unet.py:262-283) have two consumers; with ``ops.FUSE_SKIP_GRAD_ADD`` the producing gated layer
+    returns two handles of its output and adds the two incoming gradients inside sr3d_gated_act_bwd_sum instead of autograd
+    adding them in an elementwise pass of its own.  fp32: a + b is the same rounding either way, so every parameter
+    gradient must be BIT-identical; the fused form makes 4 two-gradient calls (f0, f1, f2, f3), the other none."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_config, synthetic_batch
+    cfg = make_config("mixed")
+    x, b, y = synthetic_batch(2, (16, 32, 64), 4, 78, DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(eng.ops, "FUSE_SKIP_GRAD_ADD", fused)
+        torch.manual_seed(5)
+        model = eng.make_model(cfg).to(DEV)
+        two = {"n": 0, "calls": 0}
+        orig = eng._lib.lib.sr3d_gated_act_bwd_sum
+
+        def counted(dy, dy2, *a, _orig=orig):
+            two["calls"] += 1
+            two["n"] += 1 if (dy2 is not None and getattr(dy2, "value", None)) else 0
+            return _orig(dy, dy2, *a)
+        monkeypatch.setattr(eng._lib.lib, "sr3d_gated_act_bwd_sum", counted)
+        loss = eng.make_loss(cfg)(model(x, b), y, b)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(eng._lib.lib, "sr3d_gated_act_bwd_sum", orig)
+        res[fused] = ({k: p.grad.detach().clone() for k, p in model.named_parameters()}, (two["calls"], two["n"]), float(loss.detach()))
+    assert res[True][2] == res[False][2]
+    assert res[True][1] == (9, 4) and res[False][1] == (9, 0), (res[True][1], res[False][1])     # 9 gated layers, 4 skip tensors
+    for k, g in res[True][0].items():
+        assert torch.equal(g, res[False][0][k]), k
