@@ -75,6 +75,8 @@ def make_case(cs, cout, grid, seed, batch=2, wscale=0.05):
 FWD_CASES = [
     ([5], 64, (4, 8, 32), 1), ([64, 5], 4, (4, 8, 40), 1), ([64, 1, 65], 48, (6, 10, 40), 1), ([33], 130, (5, 7, 33), 1),
     ([64, 1], 64, (8, 16, 64), 2), ([33], 40, (5, 7, 33), 2), ([40, 1, 24], 130, (7, 8, 34), 2),
+    # the x-paired stride-2 kernels of round 4: odd z / y, a partial x tile, an odd fine X over quad-loadable coarse rows
+    ([20, 1], 72, (7, 9, 40), 2), ([24], 40, (5, 9, 71), 2), ([40], 48, (6, 10, 72), 2),
 ]
 
 

@@ -93,6 +93,10 @@ S2_CASES = [
     ([48], 130, (6, 9, 70), "plain", 50.0),
     ([40, 1, 24], 32, (7, 8, 34), "gated", 1e-6),
     ([40], 48, (6, 10, 72), "plain", 1.0),        # coarse rows of 36: quad dY loads with a partial last x tile
+    # round 4, the x-paired kernels (forward: X % 4 == 0; input gradient: coarse X % 4 == 0):
+    ([20, 1], 36, (7, 9, 40), "gated", 1.0),      # odd z / y under the paired forward; 72 rows = a 64-row block + an 8-row one
+    ([24], 40, (5, 9, 71), "plain", 1.0),         # odd fine X over coarse rows of 36: paired gradient, its odd class one shorter, scalar stores
+    ([17, 1], 20, (4, 6, 36), "plain", 3.0),      # paired forward, coarse X = 18: class-form gradient next to it
 ]
 
 
