@@ -161,10 +161,11 @@ int sr3d_hwgrad(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, 
 // amax[i] (x slices 0..3) / amax[4 + i] (dy slices) = max over the 64 hashed slots another kernel exported (sr3d_hwgrad.hip)
 int sr3d_gather_absmax(const unsigned* x_absmax, int nx, const unsigned* dy_absmax, int nd, unsigned* amax, hipStream_t st);
 // few-channel (Cin <= 5) stride-1 weight gradient on the f16 MFMA (sr3d_hwgrad_fc.hip), fp32 storage
-size_t sr3d_hwgrad_fc_ws_bytes(const sr3d_conv_desc_t* d, int n_total);
-bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy);
+size_t sr3d_hwgrad_fc_ws_bytes(const sr3d_conv_desc_t* d, int n_total, bool swapped = false);
+bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, bool swapped = false);
+// swapped: few OUTPUT rows (n_total <= 5, `last`) instead of few input channels: the roles of x and dY exchanged, taps mirrored
 int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, float* dw, float* ws, hipStream_t st,
-                   const unsigned* x_absmax, const unsigned* dy_absmax);
+                   const unsigned* x_absmax, const unsigned* dy_absmax, bool swapped = false);
 // stride-2 weight gradient on the f16 / bf16 MFMA (sr3d_hwgrad_s2.hip); all d->Cin channels
 size_t sr3d_hwgrad_s2_ws_bytes(const sr3d_conv_desc_t* d, int n_total);
 bool sr3d_hwgrad_s2_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy);

@@ -21,18 +21,23 @@
 
 namespace {
 
-constexpr int FNT = 256;
 constexpr int FPITCH = 96;                     // bytes per 32-voxel fp16 row in LDS (sr3d_hwgrad.hip: conflict-free fragment reads)
-constexpr int FNB = 64;                        // rows n per workgroup
 constexpr int FXROW = 2 * 16 * FPITCH;         // one X row: [part][column (c, kx)][PITCH]
 constexpr int FXBYTES = 12 * FXROW;            // 3 planes x 4 y slots
-constexpr int FDROW = 2 * FNB * FPITCH;        // one dY row: [part][n][PITCH]
-constexpr size_t FLDS = FXBYTES + 2 * (size_t)FDROW;
+// NW waves = 16 NW rows n per workgroup: 4 (64 rows), or 5 (80 rows: the SWAPPED form of `last`, whose 69 input channels
+// play the rows -- see sr3d_hwgrad_fc)
+template <int NW>
+struct FcGeo {
+  static constexpr int NT = 64 * NW;
+  static constexpr int NB = 16 * NW;                       // rows n per workgroup
+  static constexpr int DROW = 2 * NB * FPITCH;             // one dY row: [part][n][PITCH]
+  static constexpr size_t LDS = FXBYTES + 2 * (size_t)DROW;
+};
 #ifndef HWGRAD_FC_NS
 #define HWGRAD_FC_NS 3
 #endif
 constexpr int FNS = HWGRAD_FC_NS;                         // steps the loads run ahead
-static_assert(2 * FLDS <= 160 * 1024, "two workgroups per CU");
+static_assert(2 * FcGeo<5>::LDS <= 160 * 1024, "two workgroups per CU");
 
 __host__ __device__ inline int fc_scale_exp_of(float amax) {
   const int s = split_scale_exp(amax);
@@ -50,7 +55,9 @@ struct FcParams {
   const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
 };
 
-__global__ __launch_bounds__(FNT, 2) void hwgrad_fc_kernel(const FcParams p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p) {
+  constexpr int FNT = FcGeo<NW>::NT, FNB = FcGeo<NW>::NB, FDROW = FcGeo<NW>::DROW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Xs = lds;
   unsigned char* Ds = lds + FXBYTES;
@@ -265,8 +272,11 @@ struct FcSliceMap {
 };
 
 // dW[n][c][tap] = 2^-(sx(c)+sd(n)) * sum_s slab[s][tap][n][c]  (fixed order: deterministic)
+// swapped: the kernel's rows n were the layer's INPUT channels and its few channels c the layer's output rows, with the taps
+// mirrored (sr3d_hwgrad_fc): dW[c][n][26 - tap]
 __global__ __launch_bounds__(256) void hwgrad_fc_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int N, int C,
-                                                               int ldc, int Npad, int Cpad, const float* amax, const FcSliceMap sm) {
+                                                               int ldc, int Npad, int Cpad, const float* amax, const FcSliceMap sm,
+                                                               int swapped) {
   const long long plane = (long long)Npad * Cpad;
   const long long total = (long long)N * C * 27;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -284,7 +294,10 @@ __global__ __launch_bounds__(256) void hwgrad_fc_reduce_kernel(const float* __re
       s = (((s + v0) + v1) + v2) + v3;
     }
     for (; k < S; k++) s += s0[(long long)k * 27 * plane];
-    dw[((long long)n * ldc + c) * 27 + tap] = s * mult;
+    if (swapped)
+      dw[((long long)c * ldc + n) * 27 + (26 - tap)] = s * mult;
+    else
+      dw[((long long)n * ldc + c) * 27 + tap] = s * mult;
   }
 }
 
@@ -293,10 +306,11 @@ struct FcPlan {
   long long rows_per_split;
 };
 
-FcPlan fc_plan(const sr3d_conv_desc_t* d, int n_total) {
+// n_many: rows of the kernel (the layer's rows, or its input channels in the swapped form); nw: waves per workgroup
+FcPlan fc_plan(const sr3d_conv_desc_t* d, int n_many, int nw) {
   FcPlan g;
-  g.nnb = ceil_div(n_total, FNB), g.nseg = ceil_div(d->X, 32);
-  g.Npad = g.nnb * FNB, g.Cpad = 8;
+  g.nnb = ceil_div(n_many, 16 * nw), g.nseg = ceil_div(d->X, 32);
+  g.Npad = g.nnb * 16 * nw, g.Cpad = 8;
   const long long rows = (long long)d->B * d->Z * d->Y;
   const long long cols = (long long)g.nnb * g.nseg;
   // ~4 rounds over the 512 workgroup slots of the chip, at least 24 rows per split (warm-up steps per plane segment)
@@ -310,13 +324,17 @@ FcPlan fc_plan(const sr3d_conv_desc_t* d, int n_total) {
 
 }  // namespace
 
-size_t sr3d_hwgrad_fc_ws_bytes(const sr3d_conv_desc_t* d, int n_total) {
-  const FcPlan g = fc_plan(d, n_total);
+// swapped form (few OUTPUT rows, `last`: 69 -> 4): the roles of x and dY exchanged, see sr3d_hwgrad_fc
+inline int fc_swapped_nw(int cin) { return cin > 64 && cin <= 80 ? 5 : 4; }
+
+size_t sr3d_hwgrad_fc_ws_bytes(const sr3d_conv_desc_t* d, int n_total, bool swapped) {
+  const FcPlan g = swapped ? fc_plan(d, d->Cin, fc_swapped_nw(d->Cin)) : fc_plan(d, n_total, 4);
   return 256 + (size_t)g.S * g.nseg * 27 * g.Npad * g.Cpad * 4;
 }
 
-bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy) {
-  if (d->stride != 1 || d->X % 8 != 0 || d->Cin > 5 || d->dtype != SR3D_DTYPE_F32) return false;
+bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, bool swapped) {
+  if (d->stride != 1 || d->X % 8 != 0 || d->dtype != SR3D_DTYPE_F32) return false;
+  if (swapped ? n_total > 5 : d->Cin > 5) return false;
   for (int i = 0; i < x.n; i++)
     if (reinterpret_cast<uintptr_t>(x.ptr[i]) & 15) return false;
   for (int i = 0; i < dy.n; i++)
@@ -324,9 +342,20 @@ bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCa
   return true;
 }
 
-int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, float* dw, float* ws, hipStream_t st,
-                   const unsigned* x_absmax, const unsigned* dy_absmax) {
-  const FcPlan g = fc_plan(d, n_total);
+// dW[n][c][tap] = sum_v dY[n][v] X[c][v + tap - 1].  swapped = false: few input channels (conv0), x plays the kernel's X.
+// swapped = true (round 4): few OUTPUT rows (`last`, 69 -> 4: the split weight-gradient kernel used 4 of the 32 rows of its
+// blocks, 3.6 ms).  With v' = v + tap - 1 the same sum is  sum_v' X[c][v'] dY[n][v' + (2 - tap) - 1]  -- zero padding on either
+// side gives the same terms --: the kernel runs with the layer's input channels as its ROWS and dY as its few channels, and the
+// reduce kernel writes dW[c'][n'][26 - tap'].
+int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x_real, const ChanCat& dy_real, int n_total, float* dw, float* ws, hipStream_t st,
+                   const unsigned* x_absmax_real, const unsigned* dy_absmax_real, bool swapped) {
+  const ChanCat& x = swapped ? dy_real : x_real;     // the kernel's few-channel operand
+  const ChanCat& dy = swapped ? x_real : dy_real;    // the kernel's row operand
+  const unsigned* x_absmax = swapped ? dy_absmax_real : x_absmax_real;
+  const unsigned* dy_absmax = swapped ? x_absmax_real : dy_absmax_real;
+  const int C = swapped ? n_total : d->Cin, N = swapped ? d->Cin : n_total;
+  const int nw = swapped ? fc_swapped_nw(d->Cin) : 4;
+  const FcPlan g = fc_plan(d, N, nw);
   unsigned* amax = (unsigned*)ws;
   {
     if (int rc = sr3d_zero_words(amax, 64, st)) return rc;
@@ -344,12 +373,13 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& d
   }
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<4>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<5>::LDS));
         return SR3D_OK;
       }))
     return rc;
   FcParams p{};
-  p.x = x, p.dy = dy, p.C = d->Cin, p.N = n_total;
+  p.x = x, p.dy = dy, p.C = C, p.N = N;
   p.B = d->B, p.Z = d->Z, p.Y = d->Y, p.X = d->X;
   p.nnb = g.nnb, p.nseg = g.nseg, p.S = g.S, p.rows_per_split = g.rows_per_split;
   p.Npad = g.Npad, p.Cpad = g.Cpad;
@@ -358,16 +388,20 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& d
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "few-channel weight gradient: grid too large");
   {
     SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
-    hipLaunchKernelGGL(hwgrad_fc_kernel, dim3((unsigned)nwg), dim3(FNT), FLDS, st, p);
+    constexpr size_t l4 = FcGeo<4>::LDS, l5 = FcGeo<5>::LDS;
+    if (nw == 5)
+      hipLaunchKernelGGL(hwgrad_fc_kernel<5>, dim3((unsigned)nwg), dim3(320), l5, st, p);
+    else
+      hipLaunchKernelGGL(hwgrad_fc_kernel<4>, dim3((unsigned)nwg), dim3(256), l4, st, p);
     SR3D_HIP(hipGetLastError());
   }
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
-  const long long total = (long long)n_total * d->Cin * 27;
+  const long long total = (long long)N * C * 27;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   FcSliceMap sm;
   for (int i = 0; i < SR3D_MAX_SRC; i++) sm.xcb[i] = x.cbeg[i], sm.dcb[i] = dy.cbeg[i];
-  hipLaunchKernelGGL(hwgrad_fc_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, n_total, d->Cin,
-                     d->Cin, g.Npad, g.Cpad, (const float*)amax, sm);
+  hipLaunchKernelGGL(hwgrad_fc_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, N, C,
+                     d->Cin, g.Npad, g.Cpad, (const float*)amax, sm, swapped ? 1 : 0);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

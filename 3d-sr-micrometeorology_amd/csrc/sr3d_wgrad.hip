@@ -582,6 +582,16 @@ inline bool use_hwgrad_fc(const sr3d_conv_desc_t* d, int n_total) {
   if (mode == 2) return true;
   return (long long)d->B * d->Z * d->Y * d->X >= 100000;
 }
+// ... few OUTPUT rows (`last`: 69 -> 4) on the same kernel with the roles of x and dY exchanged (round 4; before: the split
+// kernel with 4 of 32 rows used, 3.6 ms, plus the VALU kernel for the 5 channels beyond a multiple of 32)
+inline bool use_hwgrad_fc_swapped(const sr3d_conv_desc_t* d, int n_total) {
+  if (d->dtype != SR3D_DTYPE_F32 || d->stride != 1 || n_total > 5 || d->Cin < 16 || d->X % 8 != 0) return false;
+  if (getenv("SR3D_NO_FC_SWAPPED") != nullptr) return false;
+  const int mode = sr3d_hconv_mode();
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  return (long long)d->B * d->Z * d->Y * d->X >= 1000000;
+}
 // ... and the stride-2 layers on its de-interleaving form (sr3d_hwgrad_s2.hip): bf16 always; fp32 where the grid fills the
 // chip (U-Net levels 0-2; SR3D_SPLIT_F16 as above)
 inline bool use_hwgrad_s2(const sr3d_conv_desc_t* d, int n_total) {
@@ -757,6 +767,7 @@ size_t sr3d_conv3d_bwd_weight_workspace_bytes(const sr3d_conv_desc_t* d, int n_t
   if (use_hwgrad(d, n_total)) bytes = std::max(bytes, hwgrad_total_ws(d, n_total));
   if (use_hwgrad_s2(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_s2_ws_bytes(d, n_total));
   if (use_hwgrad_fc(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_fc_ws_bytes(d, n_total));
+  if (use_hwgrad_fc_swapped(d, n_total)) bytes = std::max(bytes, sr3d_hwgrad_fc_ws_bytes(d, n_total, true));
   return bytes;
 }
 
@@ -811,13 +822,26 @@ int sr3d_conv3d_bwd_weight(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs
                             (const unsigned*)dy_absmax);
     }
   }
+  if (use_hwgrad_fc_swapped(d, n_total)) {
+    ChanCat xc, dc;
+    if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
+    if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
+    for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
+    for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
+    if (sr3d_hwgrad_fc_ok(d, xc, dc, n_total, true)) {
+      SR3D_CHECK(workspace_bytes >= sr3d_hwgrad_fc_ws_bytes(d, n_total, true), SR3D_E_WORKSPACE,
+                 "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
+      return sr3d_hwgrad_fc(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream, (const unsigned*)x_absmax,
+                            (const unsigned*)dy_absmax, true);
+    }
+  }
   if (use_hwgrad_fc(d, n_total)) {
     ChanCat xc, dc;
     if (int rc = sr3d_make_cat(x_srcs, n_src, (long long)d->Z * d->Y * d->X, d->Cin, &xc, "x_srcs")) return rc;
     if (int rc = sr3d_make_cat(dy_srcs, n_dy, (long long)d->Z * d->Y * d->X, n_total, &dc, "dy_srcs")) return rc;
     for (int i = 0; i < xc.n; i++) SR3D_CHECK(xc.ptr[i], SR3D_E_ARG, "x_srcs[%d].ptr is null", i);
     for (int i = 0; i < dc.n; i++) SR3D_CHECK(dc.ptr[i], SR3D_E_ARG, "dy_srcs[%d].ptr is null", i);
-    if (sr3d_hwgrad_fc_ok(d, xc, dc)) {
+    if (sr3d_hwgrad_fc_ok(d, xc, dc, n_total)) {
       SR3D_CHECK(workspace_bytes >= sr3d_hwgrad_fc_ws_bytes(d, n_total), SR3D_E_WORKSPACE,
                  "conv3d_bwd_weight: workspace of %zu bytes is too small", workspace_bytes);
       return sr3d_hwgrad_fc(d, xc, dc, n_total, (float*)dw, (float*)workspace, (hipStream_t)stream, (const unsigned*)x_absmax,
