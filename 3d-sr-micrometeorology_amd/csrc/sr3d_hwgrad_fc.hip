@@ -19,6 +19,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <utility>
+
 namespace {
 
 constexpr int FPITCH = 96;                     // bytes per 32-voxel fp16 row in LDS (sr3d_hwgrad.hip: conflict-free fragment reads)
@@ -38,6 +40,11 @@ struct FcGeo {
 #endif
 constexpr int FNS = HWGRAD_FC_NS;                         // steps the loads run ahead
 static_assert(2 * FcGeo<5>::LDS <= 160 * 1024, "two workgroups per CU");
+
+template <class F, int... I>
+__device__ __forceinline__ void fc_static_for(F& f, const int t0, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}, t0), ...);
+}
 
 __host__ __device__ inline int fc_scale_exp_of(float amax) {
   const int s = split_scale_exp(amax);
@@ -107,14 +114,17 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
   }
   const int dxq = x0 + 8 * d_q, xxq = x0 + 8 * x_q;
 
-  float pd[FNS][8];    // dY pieces in flight
-  float px[FNS][10];   // X pieces in flight: elements -1 .. 8
+  // pieces in flight, kept AS LOADED (two quads; X: and the two neighbours apart): an array with the elements at other positions
+  // (px[10] = elements -1 .. 8, the quads at 1 .. 8) made hipcc load into temporaries and move them -- behind an s_waitcnt vmcnt(0) right after the
+  // loads were issued: wave 0 (the X stager) sat out the full memory latency in EVERY step, and the other waves at the barrier
+  // with it (2.9 us per step: conv0's weight gradient ran at 1.4 TB/s of its dY stream)
+  float pd[FNS][8];                    // dY: elements 0..7
+  float pxv[FNS][10];                  // X: elements 0..7 as loaded, then element -1 ([8]) and element 8 ([9])
 #pragma unroll
   for (int u = 0; u < FNS; u++) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) pd[u][j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 10; j++) px[u][j] = 0.f;
+    for (int j = 0; j < 8; j++) pd[u][j] = pxv[u][j] = 0.f;
+    pxv[u][8] = pxv[u][9] = 0.f;
   }
   auto load_dy = [&](const int u, const int b, const int z, const int y) {
     const bool ok = d_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
@@ -132,12 +142,12 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
     if (ok) {
       const float* r = x_src + (long long)b * x_b + (long long)z * YX + (long long)y * p.X + xxq;
       const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
-      px[u][1] = a.x, px[u][2] = a.y, px[u][3] = a.z, px[u][4] = a.w, px[u][5] = c4.x, px[u][6] = c4.y, px[u][7] = c4.z, px[u][8] = c4.w;
-      px[u][0] = xxq > 0 ? r[-1] : 0.f;
-      px[u][9] = xxq + 8 < p.X ? r[8] : 0.f;
+      pxv[u][0] = a.x, pxv[u][1] = a.y, pxv[u][2] = a.z, pxv[u][3] = a.w, pxv[u][4] = c4.x, pxv[u][5] = c4.y, pxv[u][6] = c4.z, pxv[u][7] = c4.w;
+      pxv[u][8] = xxq > 0 ? r[-1] : 0.f;
+      pxv[u][9] = xxq + 8 < p.X ? r[8] : 0.f;
     } else {
 #pragma unroll
-      for (int j = 0; j < 10; j++) px[u][j] = 0.f;
+      for (int j = 0; j < 10; j++) pxv[u][j] = 0.f;
     }
   };
   // dY row -> buffer dbuf; X row -> y slot `xslot` of its plane, columns (c, kx = 0, 1, 2)
@@ -154,8 +164,10 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
     //   kx = 0: elements -1 .. 6 = pairs 0 .. 3;  kx = 2: elements 1 .. 8 = pairs 1 .. 4;
     //   kx = 1: elements 0 .. 7 = the high half of pair k with the low half of pair k + 1 (v_alignbit)
     unsigned ph[5], pl[5];
+    split_pair(pxv[u][8], pxv[u][0], mx, ph[0], pl[0]);
 #pragma unroll
-    for (int k = 0; k < 5; k++) split_pair(px[u][2 * k], px[u][2 * k + 1], mx, ph[k], pl[k]);
+    for (int k = 1; k < 4; k++) split_pair(pxv[u][2 * k - 1], pxv[u][2 * k], mx, ph[k], pl[k]);
+    split_pair(pxv[u][7], pxv[u][9], mx, ph[4], pl[4]);
     unsigned char* d = Xs + (x_dz * 4 + xslot) * FXROW + (x_c * 3) * FPITCH + x_q * 16;
     *reinterpret_cast<u32x4*>(d) = u32x4{ph[0], ph[1], ph[2], ph[3]};
     *reinterpret_cast<u32x4*>(d + 16 * FPITCH) = u32x4{pl[0], pl[1], pl[2], pl[3]};
@@ -195,11 +207,13 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
     const int yb = (int)((r1 < pend ? r1 : pend) - plane * p.Y);
     // step t: write what was loaded in step t - NS (X rows t + 2, dY row t + 1) from ring entry u, refill that entry with
     // the rows of step t + NS, multiply row t
-    for (int t0 = ya - 3 - FNS; t0 < yb; t0 += FNS) {
-#pragma unroll
-      for (int u = 0; u < FNS; u++) {
+    // (the ring entry u as a compile-time constant of a generic lambda: with a loop variable -- `#pragma unroll` is only a
+    //  request -- the small per-entry arrays went to scratch memory)
+    auto step = [&](auto U, const int t0) {
+      {
+        constexpr int u = decltype(U)::value;
         const int t = t0 + u;
-        if (t >= yb) break;
+        if (t >= yb) return;
         if (t > ya - 4) {
           const long long rr = plane * p.Y + (t + 1);
           write_dy(u, (t + 1) & 1, ((rr >> 5) & 1) ? -1.f : 1.f);
@@ -234,7 +248,8 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-    }
+    };
+    for (int t0 = ya - 3 - FNS; t0 < yb; t0 += FNS) fc_static_for(step, t0, std::make_integer_sequence<int, FNS>{});
     r0 = plane * p.Y + yb;
   }
 
