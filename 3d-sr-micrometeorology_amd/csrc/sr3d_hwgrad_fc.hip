@@ -1,4 +1,5 @@
-// Weight gradient of a stride-1 3x3x3 convolution with FEW input channels (Cin <= 5: `conv0`, 5 -> 2 x 64) on the split-f16
+// Weight gradient of a stride-1 3x3x3 convolution with FEW input channels (Cin <= 5: `conv0`, 5 -> 2 x 64) -- or, with the roles of
+// x and dY exchanged, FEW output rows (`last`, 69 -> 4; sr3d_hwgrad_fc(..., swapped)) -- in fp32 or bf16 storage, on the split-f16
 // scheme of sr3d_hwgrad.hip (fp32 operands as two fp16 halves, three v_mfma_f32_16x16x32_f16 per product group):
 //
 //   dW[n][c][kz,ky,kx] = sum_{b,z,y,x'} dY[n][z][y][x'] * X[c][z + kz - 1][y + ky - 1][x' + kx - 1]
@@ -24,22 +25,25 @@
 namespace {
 
 constexpr int FPITCH = 96;                     // bytes per 32-voxel fp16 row in LDS (sr3d_hwgrad.hip: conflict-free fragment reads)
-constexpr int FXROW = 2 * 16 * FPITCH;         // one X row: [part][column (c, kx)][PITCH]
-constexpr int FXBYTES = 12 * FXROW;            // 3 planes x 4 y slots
+// BF = true (bf16 storage, round 4): one part, no scales, one v_mfma_f32_16x16x32_bf16 per tile; a dY piece goes to LDS as it
+// was loaded, the three shifted X columns are made with v_alignbit on the packed pairs (as in sr3d_hwgrad.hip)
 // NW waves = 16 NW rows n per workgroup: 4 (64 rows), or 5 (80 rows: the SWAPPED form of `last`, whose 69 input channels
 // play the rows -- see sr3d_hwgrad_fc)
-template <int NW>
+template <int NW, bool BF = false>
 struct FcGeo {
+  static constexpr int NP = BF ? 1 : 2;                    // operand parts
   static constexpr int NT = 64 * NW;
   static constexpr int NB = 16 * NW;                       // rows n per workgroup
-  static constexpr int DROW = 2 * NB * FPITCH;             // one dY row: [part][n][PITCH]
-  static constexpr size_t LDS = FXBYTES + 2 * (size_t)DROW;
+  static constexpr int XROW = NP * 16 * FPITCH;            // one X row: [part][column (c, kx)][PITCH]
+  static constexpr int XBYTES = 12 * XROW;                 // 3 planes x 4 y slots
+  static constexpr int DROW = NP * NB * FPITCH;            // one dY row: [part][n][PITCH]
+  static constexpr size_t LDS = XBYTES + 2 * (size_t)DROW;
 };
 #ifndef HWGRAD_FC_NS
 #define HWGRAD_FC_NS 3
 #endif
 constexpr int FNS = HWGRAD_FC_NS;                         // steps the loads run ahead
-static_assert(2 * FcGeo<5>::LDS <= 160 * 1024, "two workgroups per CU");
+static_assert(2 * FcGeo<5, false>::LDS <= 160 * 1024, "two workgroups per CU");
 
 template <class F, int... I>
 __device__ __forceinline__ void fc_static_for(F& f, const int t0, std::integer_sequence<int, I...>) {
@@ -62,9 +66,11 @@ struct FcParams {
   const float* amax;         // [0..3] = max|x slice i|, [4..7] = max|dy slice i|
 };
 
-template <int NW>
+template <int NW, bool BF>
 __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p) {
-  constexpr int FNT = FcGeo<NW>::NT, FNB = FcGeo<NW>::NB, FDROW = FcGeo<NW>::DROW;
+  using G = FcGeo<NW, BF>;
+  constexpr int FNT = G::NT, FNB = G::NB, FDROW = G::DROW, FXROW = G::XROW, FXBYTES = G::XBYTES;
+  constexpr int ESZ = BF ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Xs = lds;
   unsigned char* Ds = lds + FXBYTES;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
   // ---- staging roles: every thread one dY item (row tid / 4, 8-voxel piece tid & 3); the first 12 C threads (wave 0) also
   // one X item (plane dz, channel c, piece q)
   const int d_n = tid >> 2, d_q = tid & 3;
-  const float* d_src = nullptr;
+  const unsigned char* d_src = nullptr;   // (bytes; element size ESZ)
   long long d_b = 0;
   float md = 1.f;
   bool d_on = false;
@@ -92,24 +98,24 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
     const int n = nb * FNB + d_n;
     if (n < p.N) {
       const int si = cat_find(p.dy, n);
-      d_src = cat_ptr(p.dy, si) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX;
+      d_src = reinterpret_cast<const unsigned char*>(cat_ptr(p.dy, si)) + (long long)(n - cat_cbeg(p.dy, si)) * ZYX * ESZ;
       d_b = cat_bstride(p.dy, si);
-      md = ldexpf(1.f, fc_scale_exp_of(p.amax[4 + si]));
+      if constexpr (!BF) md = ldexpf(1.f, fc_scale_exp_of(p.amax[4 + si]));
       d_on = x0 + 8 * d_q < p.X;
     }
   }
   const bool is_x = tid < 12 * p.C;
   int x_dz = 0, x_c = 0, x_q = 0;
-  const float* x_src = nullptr;
+  const unsigned char* x_src = nullptr;
   long long x_b = 0;
   float mx = 1.f;
   bool x_on = false;
   if (is_x) {
     x_dz = tid / (4 * p.C), x_c = (tid >> 2) % p.C, x_q = tid & 3;
     const int si = cat_find(p.x, x_c);
-    x_src = cat_ptr(p.x, si) + (long long)(x_c - cat_cbeg(p.x, si)) * ZYX;
+    x_src = reinterpret_cast<const unsigned char*>(cat_ptr(p.x, si)) + (long long)(x_c - cat_cbeg(p.x, si)) * ZYX * ESZ;
     x_b = cat_bstride(p.x, si);
-    mx = ldexpf(1.f, fc_scale_exp_of(p.amax[si]));
+    if constexpr (!BF) mx = ldexpf(1.f, fc_scale_exp_of(p.amax[si]));
     x_on = x0 + 8 * x_q < p.X;
   }
   const int dxq = x0 + 8 * d_q, xxq = x0 + 8 * x_q;
@@ -126,12 +132,19 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
     for (int j = 0; j < 8; j++) pd[u][j] = pxv[u][j] = 0.f;
     pxv[u][8] = pxv[u][9] = 0.f;
   }
+  // (bf16: pd[u][0..3] / pxv[u][0..3] hold the 8 elements as 4 packed dwords, pxv[u][8] / [9] the neighbours' 16 bits)
   auto load_dy = [&](const int u, const int b, const int z, const int y) {
     const bool ok = d_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
     if (ok) {
-      const float* r = d_src + (long long)b * d_b + (long long)z * YX + (long long)y * p.X + dxq;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
-      pd[u][0] = a.x, pd[u][1] = a.y, pd[u][2] = a.z, pd[u][3] = a.w, pd[u][4] = c4.x, pd[u][5] = c4.y, pd[u][6] = c4.z, pd[u][7] = c4.w;
+      const long long off = (long long)b * d_b + (long long)z * YX + (long long)y * p.X + dxq;
+      if constexpr (BF) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(d_src + off * 2);
+        pd[u][0] = a.x, pd[u][1] = a.y, pd[u][2] = a.z, pd[u][3] = a.w;
+      } else {
+        const float* r = reinterpret_cast<const float*>(d_src) + off;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
+        pd[u][0] = a.x, pd[u][1] = a.y, pd[u][2] = a.z, pd[u][3] = a.w, pd[u][4] = c4.x, pd[u][5] = c4.y, pd[u][6] = c4.z, pd[u][7] = c4.w;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) pd[u][j] = 0.f;
@@ -140,11 +153,20 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
   auto load_x = [&](const int u, const int b, const int z, const int y) {
     const bool ok = x_on && (unsigned)z < (unsigned)p.Z && (unsigned)y < (unsigned)p.Y;
     if (ok) {
-      const float* r = x_src + (long long)b * x_b + (long long)z * YX + (long long)y * p.X + xxq;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
-      pxv[u][0] = a.x, pxv[u][1] = a.y, pxv[u][2] = a.z, pxv[u][3] = a.w, pxv[u][4] = c4.x, pxv[u][5] = c4.y, pxv[u][6] = c4.z, pxv[u][7] = c4.w;
-      pxv[u][8] = xxq > 0 ? r[-1] : 0.f;
-      pxv[u][9] = xxq + 8 < p.X ? r[8] : 0.f;
+      const long long off = (long long)b * x_b + (long long)z * YX + (long long)y * p.X + xxq;
+      if constexpr (BF) {
+        const unsigned short* r = reinterpret_cast<const unsigned short*>(x_src) + off;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r);
+        pxv[u][0] = a.x, pxv[u][1] = a.y, pxv[u][2] = a.z, pxv[u][3] = a.w;
+        pxv[u][8] = __builtin_bit_cast(float, xxq > 0 ? (unsigned)r[-1] : 0u);
+        pxv[u][9] = __builtin_bit_cast(float, xxq + 8 < p.X ? (unsigned)r[8] : 0u);
+      } else {
+        const float* r = reinterpret_cast<const float*>(x_src) + off;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r), c4 = *reinterpret_cast<const f32x4*>(r + 4);
+        pxv[u][0] = a.x, pxv[u][1] = a.y, pxv[u][2] = a.z, pxv[u][3] = a.w, pxv[u][4] = c4.x, pxv[u][5] = c4.y, pxv[u][6] = c4.z, pxv[u][7] = c4.w;
+        pxv[u][8] = xxq > 0 ? r[-1] : 0.f;
+        pxv[u][9] = xxq + 8 < p.X ? r[8] : 0.f;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 10; j++) pxv[u][j] = 0.f;
@@ -152,14 +174,32 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
   };
   // dY row -> buffer dbuf; X row -> y slot `xslot` of its plane, columns (c, kx = 0, 1, 2)
   auto write_dy = [&](const int u, const int dbuf, const float dsign) {
+    unsigned char* d = Ds + dbuf * FDROW + d_n * FPITCH + d_q * 16;
+    if constexpr (BF) {
+      const unsigned sm = dsign < 0.f ? 0x80008000u : 0u;   // sign flip of both bf16 halves
+      *reinterpret_cast<u32x4*>(d) = u32x4{__builtin_bit_cast(unsigned, pd[u][0]) ^ sm, __builtin_bit_cast(unsigned, pd[u][1]) ^ sm,
+                                           __builtin_bit_cast(unsigned, pd[u][2]) ^ sm, __builtin_bit_cast(unsigned, pd[u][3]) ^ sm};
+      return;
+    }
     unsigned h[4], l[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) split_pair(pd[u][2 * k], pd[u][2 * k + 1], md * dsign, h[k], l[k]);
-    unsigned char* d = Ds + dbuf * FDROW + d_n * FPITCH + d_q * 16;
     *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<u32x4*>(d + FNB * FPITCH) = u32x4{l[0], l[1], l[2], l[3]};
   };
   auto write_x = [&](const int u, const int xslot) {
+    unsigned char* d = Xs + (x_dz * 4 + xslot) * FXROW + (x_c * 3) * FPITCH + x_q * 16;
+    if constexpr (BF) {   // column kx holds X[x' + kx - 1]: kx = 0: elements -1 .. 6; kx = 1: 0 .. 7; kx = 2: 1 .. 8
+      const unsigned d0 = __builtin_bit_cast(unsigned, pxv[u][0]), d1 = __builtin_bit_cast(unsigned, pxv[u][1]);
+      const unsigned d2 = __builtin_bit_cast(unsigned, pxv[u][2]), d3 = __builtin_bit_cast(unsigned, pxv[u][3]);
+      const unsigned pl = __builtin_bit_cast(unsigned, pxv[u][8]) << 16, nh = __builtin_bit_cast(unsigned, pxv[u][9]);
+      *reinterpret_cast<u32x4*>(d) = u32x4{__builtin_amdgcn_alignbit(d0, pl, 16), __builtin_amdgcn_alignbit(d1, d0, 16),
+                                           __builtin_amdgcn_alignbit(d2, d1, 16), __builtin_amdgcn_alignbit(d3, d2, 16)};
+      *reinterpret_cast<u32x4*>(d + FPITCH) = u32x4{d0, d1, d2, d3};
+      *reinterpret_cast<u32x4*>(d + 2 * FPITCH) = u32x4{__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                                        __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(nh, d3, 16)};
+      return;
+    }
     // the 10 elements -1 .. 8 are split once, as the pairs (-1, 0), (1, 2), ..., (7, 8); column kx holds X[x' + kx - 1]:
     //   kx = 0: elements -1 .. 6 = pairs 0 .. 3;  kx = 2: elements 1 .. 8 = pairs 1 .. 4;
     //   kx = 1: elements 0 .. 7 = the high half of pair k with the low half of pair k + 1 (v_alignbit)
@@ -168,7 +208,6 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
 #pragma unroll
     for (int k = 1; k < 4; k++) split_pair(pxv[u][2 * k - 1], pxv[u][2 * k], mx, ph[k], pl[k]);
     split_pair(pxv[u][7], pxv[u][9], mx, ph[4], pl[4]);
-    unsigned char* d = Xs + (x_dz * 4 + xslot) * FXROW + (x_c * 3) * FPITCH + x_q * 16;
     *reinterpret_cast<u32x4*>(d) = u32x4{ph[0], ph[1], ph[2], ph[3]};
     *reinterpret_cast<u32x4*>(d + 16 * FPITCH) = u32x4{pl[0], pl[1], pl[2], pl[3]};
     u32x4 mh, ml;
@@ -232,16 +271,23 @@ __global__ __launch_bounds__(64 * NW, 2) void hwgrad_fc_kernel(const FcParams p)
             acc_sign = sgn;
           }
           const unsigned char* da = Ds + (t & 1) * FDROW + fa;
-          const h8 ah = *reinterpret_cast<const h8*>(da), al = *reinterpret_cast<const h8*>(da + FNB * FPITCH);
+          const h8 ah = *reinterpret_cast<const h8*>(da);
+          h8 al = ah;
+          if constexpr (!BF) al = *reinterpret_cast<const h8*>(da + FNB * FPITCH);
 #pragma unroll
           for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
               const unsigned char* xb = Xs + (a * 4 + ((t + k - 1) & 3)) * FXROW + fr;
-              const h8 bh = *reinterpret_cast<const h8*>(xb), bl = *reinterpret_cast<const h8*>(xb + 16 * FPITCH);
-              acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a][k], 0, 0, 0);
-              acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a][k], 0, 0, 0);
-              acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a][k], 0, 0, 0);
+              const h8 bh = *reinterpret_cast<const h8*>(xb);
+              if constexpr (BF) {
+                acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ah), __builtin_bit_cast(bf8, bh), acc[a][k], 0, 0, 0);
+              } else {
+                const h8 bl = *reinterpret_cast<const h8*>(xb + 16 * FPITCH);
+                acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[a][k], 0, 0, 0);
+                acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[a][k], 0, 0, 0);
+                acc[a][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[a][k], 0, 0, 0);
+              }
             }
         }
         // (not __syncthreads(): that would drain vmcnt and expose the latency of the loads issued above in every step)
@@ -299,7 +345,7 @@ __global__ __launch_bounds__(256) void hwgrad_fc_reduce_kernel(const float* __re
     const long long r = e / C;
     const int n = (int)(r % N), tap = (int)(r / N);
     const int xi = (c >= sm.xcb[1]) + (c >= sm.xcb[2]) + (c >= sm.xcb[3]), di = (n >= sm.dcb[1]) + (n >= sm.dcb[2]) + (n >= sm.dcb[3]);
-    const float mult = ldexpf(1.f, -(fc_scale_exp_of(amax[xi]) + fc_scale_exp_of(amax[4 + di])));
+    const float mult = amax ? ldexpf(1.f, -(fc_scale_exp_of(amax[xi]) + fc_scale_exp_of(amax[4 + di]))) : 1.f;   // (bf16: unscaled)
     const float* s0 = slab + (long long)tap * plane + (long long)n * Cpad + c;
     float s = 0.f;
     int k = 0;
@@ -348,7 +394,7 @@ size_t sr3d_hwgrad_fc_ws_bytes(const sr3d_conv_desc_t* d, int n_total, bool swap
 }
 
 bool sr3d_hwgrad_fc_ok(const sr3d_conv_desc_t* d, const ChanCat& x, const ChanCat& dy, int n_total, bool swapped) {
-  if (d->stride != 1 || d->X % 8 != 0 || d->dtype != SR3D_DTYPE_F32) return false;
+  if (d->stride != 1 || d->X % 8 != 0) return false;
   if (swapped ? n_total > 5 : d->Cin > 5) return false;
   for (int i = 0; i < x.n; i++)
     if (reinterpret_cast<uintptr_t>(x.ptr[i]) & 15) return false;
@@ -371,8 +417,9 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x_real, const ChanC
   const int C = swapped ? n_total : d->Cin, N = swapped ? d->Cin : n_total;
   const int nw = swapped ? fc_swapped_nw(d->Cin) : 4;
   const FcPlan g = fc_plan(d, N, nw);
+  const bool bf = d->dtype == SR3D_DTYPE_BF16;
   unsigned* amax = (unsigned*)ws;
-  {
+  if (!bf) {
     if (int rc = sr3d_zero_words(amax, 64, st)) return rc;
     SrProfScope prof(SR3D_PROF_DATA, 0.0, st);
     if (x_absmax == nullptr)
@@ -388,8 +435,10 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x_real, const ChanC
   }
   static SrPerDevice setup;   // (the attribute is per device, not per thread)
   if (int rc = setup.once([&]() -> int {
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<4>::LDS));
-        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<5>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<4, false>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<5, false>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<4, true>::LDS));
+        SR3D_HIP(hipFuncSetAttribute((const void*)hwgrad_fc_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcGeo<5, true>::LDS));
         return SR3D_OK;
       }))
     return rc;
@@ -398,16 +447,22 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x_real, const ChanC
   p.B = d->B, p.Z = d->Z, p.Y = d->Y, p.X = d->X;
   p.nnb = g.nnb, p.nseg = g.nseg, p.S = g.S, p.rows_per_split = g.rows_per_split;
   p.Npad = g.Npad, p.Cpad = g.Cpad;
-  p.slab = ws + 64, p.amax = (const float*)amax;
+  p.slab = ws + 64, p.amax = bf ? nullptr : (const float*)amax;
   const long long nwg = (long long)g.nnb * g.nseg * g.S;
   SR3D_CHECK(nwg < (1ll << 31), SR3D_E_ARG, "few-channel weight gradient: grid too large");
   {
     SrProfScope prof(SR3D_PROF_WGRAD, 2.0 * 27 * d->Cin * (double)n_total * (double)d->Z * d->Y * d->X * d->B, st);
-    constexpr size_t l4 = FcGeo<4>::LDS, l5 = FcGeo<5>::LDS;
-    if (nw == 5)
-      hipLaunchKernelGGL(hwgrad_fc_kernel<5>, dim3((unsigned)nwg), dim3(320), l5, st, p);
-    else
-      hipLaunchKernelGGL(hwgrad_fc_kernel<4>, dim3((unsigned)nwg), dim3(256), l4, st, p);
+    constexpr size_t l4 = FcGeo<4, false>::LDS, l5 = FcGeo<5, false>::LDS, l4b = FcGeo<4, true>::LDS, l5b = FcGeo<5, true>::LDS;
+    if (bf) {
+      if (nw == 5)
+        hipLaunchKernelGGL((hwgrad_fc_kernel<5, true>), dim3((unsigned)nwg), dim3(320), l5b, st, p);
+      else
+        hipLaunchKernelGGL((hwgrad_fc_kernel<4, true>), dim3((unsigned)nwg), dim3(256), l4b, st, p);
+    } else if (nw == 5) {
+      hipLaunchKernelGGL((hwgrad_fc_kernel<5, false>), dim3((unsigned)nwg), dim3(320), l5, st, p);
+    } else {
+      hipLaunchKernelGGL((hwgrad_fc_kernel<4, false>), dim3((unsigned)nwg), dim3(256), l4, st, p);
+    }
     SR3D_HIP(hipGetLastError());
   }
   SrProfScope prof(SR3D_PROF_PACK, 4.0 * ((double)g.S * g.nseg + 1) * 27 * g.Npad * g.Cpad, st);
@@ -416,7 +471,7 @@ int sr3d_hwgrad_fc(const sr3d_conv_desc_t* d, const ChanCat& x_real, const ChanC
   FcSliceMap sm;
   for (int i = 0; i < SR3D_MAX_SRC; i++) sm.xcb[i] = x.cbeg[i], sm.dcb[i] = dy.cbeg[i];
   hipLaunchKernelGGL(hwgrad_fc_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, dw, g.S * g.nseg, N, C,
-                     d->Cin, g.Npad, g.Cpad, (const float*)amax, sm, swapped ? 1 : 0);
+                     d->Cin, g.Npad, g.Cpad, bf ? (const float*)nullptr : (const float*)amax, sm, swapped ? 1 : 0);
   SR3D_HIP(hipGetLastError());
   return SR3D_OK;
 }

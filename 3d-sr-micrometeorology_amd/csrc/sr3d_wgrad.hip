@@ -576,7 +576,8 @@ inline bool use_hwgrad(const sr3d_conv_desc_t* d, int n_total) {
 }
 // ... few input channels (conv0: 5) on its (channel, kx)-column form (sr3d_hwgrad_fc.hip), fp32 storage, grids that fill the chip
 inline bool use_hwgrad_fc(const sr3d_conv_desc_t* d, int n_total) {
-  if (d->dtype != SR3D_DTYPE_F32 || d->stride != 1 || d->Cin > 5 || n_total < 16 || d->X % 8 != 0) return false;
+  if (d->stride != 1 || d->Cin > 5 || n_total < 16 || d->X % 8 != 0) return false;
+  if (d->dtype == SR3D_DTYPE_BF16) return getenv("SR3D_NO_FC_BF16") == nullptr;   // (round 4: the bf16 form of the kernel, any size)
   const int mode = sr3d_hconv_mode();
   if (mode == 0) return false;
   if (mode == 2) return true;
@@ -585,8 +586,9 @@ inline bool use_hwgrad_fc(const sr3d_conv_desc_t* d, int n_total) {
 // ... few OUTPUT rows (`last`: 69 -> 4) on the same kernel with the roles of x and dY exchanged (round 4; before: the split
 // kernel with 4 of 32 rows used, 3.6 ms, plus the VALU kernel for the 5 channels beyond a multiple of 32)
 inline bool use_hwgrad_fc_swapped(const sr3d_conv_desc_t* d, int n_total) {
-  if (d->dtype != SR3D_DTYPE_F32 || d->stride != 1 || n_total > 5 || d->Cin < 16 || d->X % 8 != 0) return false;
+  if (d->stride != 1 || n_total > 5 || d->Cin < 16 || d->X % 8 != 0) return false;
   if (getenv("SR3D_NO_FC_SWAPPED") != nullptr) return false;
+  if (d->dtype == SR3D_DTYPE_BF16) return getenv("SR3D_NO_FC_BF16") == nullptr;
   const int mode = sr3d_hconv_mode();
   if (mode == 0) return false;
   if (mode == 2) return true;

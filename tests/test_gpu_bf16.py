@@ -177,6 +177,7 @@ def test_bf16_gated_conv_forward_and_saved_tensors_exact(eng, cs, cout, grid, st
     ([64], 1, 24, (4, 12, 32), 1), ([32, 1, 33], 1, 130, (5, 9, 72), 1), ([64, 2], 2, 36, (3, 26, 40), 1),
     ([40], 1, 64, (5, 7, 20), 1), ([65], 2, 32, (8, 12, 32), 2), ([5], 2, 64, (4, 8, 64), 1), ([64, 5], 1, 4, (4, 8, 32), 1),
     ([64, 1], 2, 64, (7, 9, 80), 2), ([33], 1, 130, (6, 10, 34), 2),
+    ([96, 3], 1, 4, (4, 8, 32), 1), ([3], 1, 40, (5, 6, 40), 1),      # hwgrad_fc<bf16>: few rows over two 64-channel blocks; few channels
 ])
 def test_bf16_weight_gradient_kernels_vs_fp64(eng, cs, n_dy, cout, grid, stride):
     from sr3d_amd import _lib as L

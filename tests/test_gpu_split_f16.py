@@ -129,7 +129,8 @@ def test_split_f16_stride2_layers_vs_fp64(eng, forced, cs, cout, grid, kind, sca
     ([32, 1, 33], 130, (5, 9, 72), "plain"),
     ([40], 64, (7, 30, 48), "plain"),
     ([64, 2], 36, (3, 26, 40), "gated"),
-    ([64, 5], 4, (4, 12, 32), "plain"),        # the `last` layer's shape: 4 rows of a 32-row block
+    ([64, 5], 4, (4, 12, 32), "plain"),        # the `last` layer's shape: 4 rows (round 4: hwgrad_fc with x and dY exchanged, 80-row workgroups)
+    ([96, 3], 3, (4, 12, 32), "plain"),        # ... 99 input channels: two 64-row blocks of that form
 ])
 def test_split_f16_weight_gradient_vs_fp64(eng, forced, cs, cout, grid, kind):
     xs, wf, wg, bias, ref, gy = _ref_and_inputs(cs, cout, grid, kind, 1.0, seed=3 * sum(cs) + cout)
