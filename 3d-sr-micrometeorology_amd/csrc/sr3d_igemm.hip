@@ -317,6 +317,9 @@ struct SmallFwdParams {
   int unsh_C, unsh_c0;
 };
 
+// NN = output channels computed (1, 2 or 4): the remainder rows of the decoder's input gradients are ONE row each (193 = 3 x 64 + 1),
+// and with four accumulator columns three quarters of that launch's FMAs multiplied zeros
+template <int NN>
 __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p) {
   constexpr int TZ = 4, TY = 8, RW = 40, RQ = RW / 4, HY = TY + 2, HZ = TZ + 2, KC = 4;
   constexpr int PZ = HY * RW, PC = HZ * PZ;
@@ -335,11 +338,11 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
   bool vec = p.X % 4 == 0;
   for (int i = 0; i < p.in.n; i++) vec = vec && (reinterpret_cast<uintptr_t>(p.in.ptr[i]) & 15) == 0;
 
-  float acc[4][4];  // [voxel i][channel n]
+  float acc[4][NN];  // [voxel i][channel n]
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int n = 0; n < 4; n++) acc[i][n] = 0.f;
+    for (int n = 0; n < NN; n++) acc[i][n] = 0.f;
 
   const int nchunks = (p.K + KC - 1) / KC;
   for (int chunk = 0; chunk < nchunks; chunk++) {
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
           for (int kx = 0; kx < 3; kx++) {
             const float* wt = wc + ((kz * 3 + ky) * 3 + kx) * 4;
 #pragma unroll
-            for (int n = 0; n < 4; n++) {
+            for (int n = 0; n < NN; n++) {
               const float wv = wt[n];
 #pragma unroll
               for (int i = 0; i < 4; i++) acc[i][n] += h[kx + i] * wv;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
   float amax_act = 0.f;
   if (gz < p.Z && gy < p.Y) {
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
+    for (int n = 0; n < NN; n++) {
       if (n >= p.N) break;
       const float bv = p.bias ? p.bias[n] : 0.f;
       const long long fine = (long long)b * p.y_bstride + ((long long)n * p.Z + gz) * p.Y * p.X + (long long)gy * p.X + gx;
@@ -442,6 +445,16 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
     for (int off = 32; off > 0; off >>= 1) amax_act = fmaxf(amax_act, __shfl_xor(amax_act, off, 64));
     if (lane == 0 && amax_act > 0.f) atomicMax(p.act_amax + (blockIdx.x & 63), __float_as_uint(amax_act));
   }
+}
+
+inline void launch_smalln_fwd(const SmallFwdParams& q, int B, hipStream_t st) {
+  const dim3 grid(q.ntz * q.nty * q.ntx, B);
+  if (q.N == 1)
+    hipLaunchKernelGGL(smalln_fwd_kernel<1>, grid, dim3(256), 0, st, q);
+  else if (q.N == 2)
+    hipLaunchKernelGGL(smalln_fwd_kernel<2>, grid, dim3(256), 0, st, q);
+  else
+    hipLaunchKernelGGL(smalln_fwd_kernel<4>, grid, dim3(256), 0, st, q);
 }
 
 // w[(c*27 + t)*4 + n] = W[n][c][t]
@@ -849,7 +862,7 @@ int sr3d_conv3d_fwd(const sr3d_conv_desc_t* d, const sr3d_slice_t* x_srcs, int n
     q.w = (const float*)w_packed, q.bias = (const float*)bias, q.y = (float*)y, q.act = act;
     q.y_bstride = (long long)d->Cout * d->Z * d->Y * d->X;
     SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_fwd: batch too large");
-    hipLaunchKernelGGL(smalln_fwd_kernel, dim3(q.ntz * q.nty * q.ntx, d->B), dim3(256), 0, (hipStream_t)stream, q);
+    launch_smalln_fwd(q, d->B, (hipStream_t)stream);
     SR3D_HIP(hipGetLastError());
     return SR3D_OK;
   }
@@ -1103,7 +1116,7 @@ static int bwd_data_impl(const sr3d_conv_desc_t* d, const sr3d_slice_t* dy_srcs,
         if (act_unsh) sq.y = (float*)last.ptr, sq.unsh_C = last.channels, sq.unsh_c0 = last.channels - rem;
       }
       SR3D_CHECK(d->B <= 65535, SR3D_E_ARG, "conv3d_bwd_data: batch too large");
-      hipLaunchKernelGGL(smalln_fwd_kernel, dim3(sq.ntz * sq.nty * sq.ntx, d->B), dim3(256), 0, st, sq);
+      launch_smalln_fwd(sq, d->B, st);
       SR3D_HIP(hipGetLastError());
     }
     return SR3D_OK;
