@@ -78,7 +78,14 @@ __global__ __launch_bounds__(WNT) void hwgrad_s2_kernel(const Hw2Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < WNT / 64);
 
-  int v = blockIdx.x;
+  // the nnb x ncb workgroups of one (segment, split) read the SAME X and dY rows: consecutive virtual ids on ONE XCD (its L2), as in
+  // sr3d_hwgrad.hip (6.6 GB fetched per launch for 3.1 GB of operands with the plain order, profiles/r04_pmc_hbm_traffic.json)
+  int v;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int nb = v % p.nnb;
   v /= p.nnb;
   const int cb = v % p.ncb;

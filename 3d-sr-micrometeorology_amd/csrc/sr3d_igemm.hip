@@ -327,7 +327,15 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const SmallFwdParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xq = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
-  int tile = blockIdx.x;
+  // neighbouring tiles share halo rows: consecutive tile ids run on ONE XCD (block ids are dealt round-robin over the 8 XCDs, each
+  // with its own L2), as in sr3d_hconv.hip -- with the plain order `last`'s forward fetched 11 GB for 2.3 GB of operands
+  // (profiles/r04_pmc_hbm_traffic.json) at 5.2 TB/s: it was HBM-bound on its own over-fetch
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int tix = tile % p.ntx;
   tile /= p.ntx;
   const int tiy = tile % p.nty;
