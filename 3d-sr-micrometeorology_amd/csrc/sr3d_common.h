@@ -105,6 +105,7 @@ struct SrHconvParams {
   // act_amax[64] (optional, fp32: the scale of that layer's split-f16 weight gradient)
   int vec_epi;         // set by sr3d_hconv_launch: X % 4 == 0 and every destination / y / save pointer 16-byte aligned -> the plain
                        // and gated epilogues transpose their 16 x 16 tiles through LDS and store 4 x-neighbours at a time
+  int itail;           // set by sr3d_hconv_launch: the last chunk (1 .. 5 channels) runs in im2col form (sr3d_hconv.hip)
   int out_f32;         // bf16 storage, plain epilogue: the destinations are fp32 tensors (the network's prediction: `last`)
   const void* act_y;
   int act_unsh;        // the fused slice is stored in the producer's SHUFFLED layout (8 C channels on the coarse grid); vec_epi only

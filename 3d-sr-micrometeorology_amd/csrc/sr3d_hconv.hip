@@ -115,7 +115,21 @@ __device__ __forceinline__ void hconv_static_for(F& f, T tag, std::integer_seque
 // HALF-CHUNK TAIL (split form): when the last chunk holds 1 .. 8 channels (K = 129, 194, 258: a mask or an odd feature
 // channel behind a multiple of 16; K = 5 and 4: conv0 and the input gradient of `last`), its MFMAs take K = 4 taps x 8
 // channels instead of 2 taps x 16: 7 phases instead of 14, no zero channel half multiplied (K = 129: 5.6 % of the layer's MFMAs).
-__host__ __device__ inline bool hconv_tail(int K, bool bf) { return !bf && (K & 15) >= 1 && (K & 15) <= 8; }
+__host__ __device__ inline bool hconv_tail(int K, bool bf, bool itail = false) { return !bf && !itail && (K & 15) >= 1 && (K & 15) <= 8; }
+// IM2COL TAIL (round 4, both forms): when the last chunk holds 1 .. 5 channels -- the mask channel behind 128 or 256 features
+// (K = 129, 257), two odd channels (194, 258, 386, 514), `last`'s input gradient (4), conv0 (5) -- the K = 32 of one MFMA are
+// the 27 TAPS of ONE of these channels (+ 5 zeros) instead of 2 taps x 16 channels: one MFMA group per tail channel instead of
+// 7 (half-chunk tail) or 14 (bf16 had no tail form at all: K = 129 cost 9 x 14 = 126 groups for 113 of work).  The weights
+// of such a group are packed as [row][tap]; the B operand -- 8 taps of one channel at the lane's voxel -- is gathered from the
+// halo with 2-byte LDS reads at the 8 tap offsets of the lane's K group (a 32-entry table in LDS): 32 (split: 64) small reads
+// per group against the 6 .. 13 groups of 8 (16) ds_read_b128 + 16 (48) MFMAs it replaces.
+constexpr int kITailMax = 5;
+// (split form: only for 1 - 2 tail channels -- against the half-chunk tail's 7 groups the gather pays up to there: K = 129 forward
+//  19.5 -> 19.15 ms, K = 5 (conv0) 2.65 -> 2.85 ms, profiles/r04az_ab_hconv_im2col_tail.log; bf16, against 14 groups, gains at 1 .. 5)
+inline bool hconv_itail_host(int K, bool bf) {
+  const int nt = K & 15;
+  return nt >= 1 && nt <= (bf ? kITailMax : 2) && getenv("SR3D_HCONV_NO_ITAIL") == nullptr;
+}
 
 // s_waitcnt vmcnt(n) lgkmcnt(0) for the counts the kernel uses (n folds to a constant in the unrolled phase loop)
 __device__ __forceinline__ void hconv_wait_vm(const int n) {
@@ -514,8 +528,17 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
   // ---- prologue
   constexpr int NWB = G::NWB, AHEAD = NWB - 1;
   constexpr int PP = G::PP, NPH = G::NPH;
-  const bool tail = hconv_tail(p.K, BF);
-  const int nphases = p.nchunks * NPH - (tail ? NPH / 2 : 0);
+  const bool itail = p.itail != 0;
+  const bool tail = hconv_tail(p.K, BF, itail);
+  const int nt = p.K & 15;                                  // channels of the last chunk (itail: 1 .. 5)
+  const int nph_it = (nt + PP - 1) / PP;                    // its phases in the im2col form: PP channels each
+  const int nphases = itail ? (p.nchunks - 1) * NPH + nph_it : p.nchunks * NPH - (tail ? NPH / 2 : 0);
+  // tap offsets for the im2col tail's gather: behind the exchange slots in the padding of halo plane 0
+  int* lut = reinterpret_cast<int*>(Hs + HVOX * 16 + 64);
+  if (itail && tid < 32) {   // (here, in front of the prologue's barriers: a one-chunk layer -- conv0 -- has no other before its tail)
+    const int u = tid > 26 ? 26 : tid;   // taps 27 .. 31 read where tap 26 does (their weights are zero)
+    lut[tid] = (((u / 9) * HHY + (u / 3) % 3) * HHX + u % 3) * 16;
+  }
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
     if (a < nphases) dma_w(a, Ws + a * G::WPH);
@@ -537,7 +560,7 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
   int wb = 0;            // weight buffer of the current phase = phase % NWB (running: NWB = 3 is not a power of two)
   auto wb_plus = [](const int w, const int a) { const int t = w + a; return t >= NWB ? t - NWB : t; };
   int chunk = 0;
-  const int nfull = p.nchunks - (tail ? 1 : 0);   // full 16-channel chunks; the half-chunk tail follows the loop
+  const int nfull = p.nchunks - ((tail || itail) ? 1 : 0);   // full 16-channel chunks; the tail follows the loop
   // (the phases as instantiations of one generic lambda: kzy is a compile-time constant in each -- a `#pragma unroll` loop
   // is only a request, and rolled the next chunk's raw rows and their split form would both be live in every phase)
   auto phase_body = [&](auto kz, auto tl) {
@@ -703,6 +726,67 @@ __global__ __launch_bounds__(HNT, (BF && HCONV_NWB_BF == 3) ? 3 : 2) void hconv_
   }
   if constexpr (!BF) {   // the half-chunk tail (the refill state of the loop above is dead here)
     if (tail) hconv_static_for(phase_body, std::true_type{}, std::make_integer_sequence<int, NPH / 2>{});
+  }
+  if (itail) {   // the im2col tail: phase ph = tail channels ph * PP .. + PP - 1, one MFMA group (K = its 27 taps) each
+    const int g = lane >> 4;
+    int toff[8];
+    {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const i32x4 a = *reinterpret_cast<const i32x4*>(lut + 8 * g), c4 = *reinterpret_cast<const i32x4*>(lut + 8 * g + 4);
+      toff[0] = a[0], toff[1] = a[1], toff[2] = a[2], toff[3] = a[3], toff[4] = c4[0], toff[5] = c4[1], toff[6] = c4[2], toff[7] = c4[3];
+    }
+    for (int ph = 0; ph < nph_it; ph++) {
+      const unsigned char* W0 = Ws + wb * G::WPH + abase;
+      if (phase + AHEAD < nphases) dma_w(phase + AHEAD, Ws + wb_plus(wb, AHEAD) * G::WPH);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sub = 0; sub < PP; sub++) {
+        const int sc = ph * PP + sub;   // tail channel (wave-uniform)
+        if (sc >= nt) break;
+        const unsigned char* W = W0 + sub * G::WPHASE;
+        h8 fb[NP][4];
+#pragma unroll
+        for (int part = 0; part < NP; part++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned char* hb = Hs + part * (2 * HPLANE) + (bbase[j] - ((lane >> 4) & 1) * HPLANE) + sc * 2;   // channel half 0
+            u32x4 pk;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              pk[k] = (unsigned)*reinterpret_cast<const unsigned short*>(hb + toff[2 * k]) |
+                      ((unsigned)*reinterpret_cast<const unsigned short*>(hb + toff[2 * k + 1]) << 16);
+            fb[part][j] = __builtin_bit_cast(h8, pk);
+          }
+#pragma unroll
+        for (int ih = 0; ih < NRT; ih += 2) {
+          h8 fa[NP][2];
+#pragma unroll
+          for (int part = 0; part < NP; part++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + (part * NRT + ih + i) * 1024);
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if constexpr (BF) {
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[0][i]), __builtin_bit_cast(bf8, fb[0][j]),
+                                                                         acc[ih + i][j], 0, 0, 0);
+              } else {
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[NP - 1][j], acc[ih + i][j], 0, 0, 0);
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[NP - 1][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc[ih + i][j], 0, 0, 0);
+              }
+            }
+        }
+      }
+      {
+        constexpr int ND = (G::PP * G::PIECES + 3) / 4;
+        hconv_wait_vm(phase + AHEAD >= nphases ? 0 : ND * (AHEAD - 1));
+      }
+      __builtin_amdgcn_s_barrier();
+      wb = wb_plus(wb, 1);
+      phase++;
+    }
   }
 
   if (export_max && lane == 0) {   // (bits of a non-negative float order like unsigned integers)
@@ -1039,6 +1123,7 @@ struct HPackParams {
   _Float16* img;
   int Cout, Cin, kind, K, N, nchunks, nblk, RT, n_off;
   int bf;   // 1: one bf16 part per weight (no scaling) instead of the [hi | lo] fp16 pair
+  int itail;   // 1: the last chunk (1 .. 5 channels) in im2col form (see hconv_itail_host)
   int unsh_C;   // > 0: rows in voxel-unshuffle order, GEMM row r = c * 8 + f holds output channel f * unsh_C + c
   int rbeg[SR3D_MAX_SRC + 1];
   int cbeg[SR3D_MAX_SRC];
@@ -1065,12 +1150,19 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     const int chunk = r % p.nchunks;
     const int nb = r / p.nchunks;
     const int n = p.n_off + nb * (32 * p.RT) + rt * 16 + row;
-    const bool tailc = hconv_tail(p.K, p.bf != 0) && chunk + 1 == p.nchunks;   // half-chunk tail: 4 taps x 8 channels per MFMA
+    const bool tailc = hconv_tail(p.K, p.bf != 0, p.itail != 0) && chunk + 1 == p.nchunks;   // half-chunk tail: 4 taps x 8 channels per MFMA
     if (tailc && h == 1) continue;                                             // (its second channel half does not exist)
+    const bool itc = p.itail != 0 && chunk + 1 == p.nchunks;   // im2col tail: the item (tap, h) stands for (tail channel sc, K group g)
+    int it_sc = 0, it_g = 0;
+    if (itc) {
+      const int idx = tap * 2 + h;
+      if (idx >= 4 * (p.K & 15)) continue;
+      it_sc = idx >> 2, it_g = idx & 3;
+    }
     const float* w = nullptr;   // -> w[.][k = 0][tap 0]; element (k, tap) at w[k * kstride + tapidx]
     long long kstride = 27;
     int tapidx = tap;
-    if (tap < 27) {
+    if (tap < 27 || itc) {
       if (p.kind == SR3D_PACK_FWD) {
         // (unshuffle order: the two x-neighbours (f & 1) of an output voxel sit in adjacent accumulator registers)
         const int nsrc = p.unsh_C > 0 ? (n & 7) * p.unsh_C + (n >> 3) : n;
@@ -1090,7 +1182,13 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     bf8 wb;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int k = chunk * HKC + h * 8 + j;
+      int k = chunk * HKC + h * 8 + j;
+      if (itc) {   // element j = tap 8 g + j of tail channel sc (taps 27 .. 31: zeros)
+        k = chunk * HKC + it_sc;
+        const int t = 8 * it_g + j;
+        tapidx = (p.kind == SR3D_PACK_BWD || p.kind == SR3D_PACK_BWD_GATED) ? 26 - t : t;
+        if (t > 26) k = p.K;   // -> 0
+      }
       float val = 0.f;
       if (w != nullptr && k < p.K) {
         if (p.kind == SR3D_PACK_BWD || p.kind == SR3D_PACK_BWD_GATED) {
@@ -1112,8 +1210,9 @@ __global__ __launch_bounds__(256) void hconv_pack_kernel(const HPackParams p) {
     int l = row + 16 * (2 * (tap & 1) + h);
     int phs = tap / 2;
     if (tailc) l = row + 16 * (tap & 3), phs = tap / 4;   // lane group = tap of the quad; phases 0 .. 6 of the chunk
+    if (itc) l = row + 16 * it_g, phs = it_sc;            // K group = 8 taps of the channel; one pair slot per tail channel
     if (p.bf) {
-      const long long frag = (((long long)nb * p.nchunks + chunk) * 14 + tap / 2) * (2 * p.RT) + rt;
+      const long long frag = (((long long)nb * p.nchunks + chunk) * 14 + (itc ? phs : tap / 2)) * (2 * p.RT) + rt;
       *reinterpret_cast<bf8*>(p.img + frag * 512 + l * 8) = wb;
       continue;
     }
@@ -1173,6 +1272,7 @@ int sr3d_hconv_pack(int kind, int Cout, int Cin, int rows, int K, const float* w
   }
   HPackParams p{};
   p.bf = bf ? 1 : 0;
+  p.itail = hconv_itail_host(K, bf) ? 1 : 0;
   p.hdr = hdr, p.unsh_C = unsh_C;
   SR3D_CHECK(unsh_C == 0 || (kind == SR3D_PACK_FWD && rows == 8 * unsh_C), SR3D_E_ARG, "hconv pack: unshuffle order needs a plain forward image with 8 * C rows");
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
@@ -1243,6 +1343,7 @@ int sr3d_hconv_launch(SrHconvParams& p, const void* image, int B, bool bf, hipSt
   p.wimg = (const unsigned char*)image + 64;
   p.ntz = ceil_div(p.Z, 2), p.nty = ceil_div(p.Y, 4), p.ntx = ceil_div(p.X, 32);
   p.nchunks = ceil_div(p.K, HKC);
+  p.itail = hconv_itail_host(p.K, bf) ? 1 : 0;   // (sr3d_hconv_pack asked the same question)
   int n2, n1;
   row_split(p.N, &n2, &n1);
   const long long nsp = (long long)p.ntz * p.nty * p.ntx;

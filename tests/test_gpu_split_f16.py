@@ -61,7 +61,8 @@ CASES = [
     ([36, 1], 40, (5, 6, 35), "gated", 1.0),
     ([4, 1], 64, (6, 10, 40), "gated", 1.0),     # conv0: K = 5 is ONE half chunk (4 taps x 8 channels per MFMA, 7 phases)
     ([64, 5], 4, (6, 10, 40), "plain", 1.0),     # `last`: the input gradient has K = 4
-    ([128, 1], 40, (4, 8, 32), "plain", 1.0),    # 8 full chunks + a half-chunk tail of one channel
+    ([128, 1], 40, (4, 8, 32), "plain", 1.0),    # 8 full chunks + a tail of one channel (round 4: im2col form, K = its 27 taps)
+    ([32, 2], 130, (4, 8, 36), "plain", 1.0),    # ... of two channels, forward; 130 rows: the input gradient's K = 130 has one too
 ]
 
 
