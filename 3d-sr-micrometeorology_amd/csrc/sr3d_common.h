@@ -145,6 +145,7 @@ struct SrHconvS2Params {
   long long cls_blk[8];
   int cZ[8], cY[8], cX[8];
   unsigned* amax_out;  // mode 1, optional [SR3D_MAX_SRC][64]: max |x| per K-side slice (as SrHconvParams.amax_out; fp32 only)
+  int itail;           // paired forward, set by the launch: the last chunk (1 - 2 channels) in im2col form
 };
 int sr3d_absmax_launch(const float* x, long long n, unsigned* slot, hipStream_t st);   // max |x| into *slot (sr3d_hconv.hip)
 size_t sr3d_hconv_s2_image_bytes(int rows, int K, bool bf = false);

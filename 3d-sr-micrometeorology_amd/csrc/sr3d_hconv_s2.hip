@@ -764,10 +764,20 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
   const int abase = lane * 16;
 
   // ---- prologue
+  // IM2COL TAIL (sr3d_hconv.hip): when the last 16-channel chunk holds 1 - 2 channels (every stride-2 layer of the model: K = 64 / 128 /
+  // 256 features + the mask) the K = 16 of an MFMA are taps of ONE of them -- the T <= 12 taps of the pair in list order -- instead
+  // of 16 channels at one tap: nt groups per (pair, tail chunk) instead of T, 4 nt instead of 27 per tail chunk (K = 65: 5 chunks
+  // of work became 4.15).  The B operand is gathered with 2-byte LDS reads at the lane's 8 tap offsets.
+  const bool itail = p.itail != 0;
+  const int nt = p.K & 15;
   int pp = 0, cc_cur = 0;
-  auto pp_n_of = [&](const int pp_, const int cc_) { const int q = cc_ + 1 == cpc ? pp_ + 1 : pp_; return q > 3 ? 3 : q; };
-  int woff = 0, gph = 0;
-  dma_w(0, (TPP < 3 ? TPP : 3) * NP * RT, Ws);   // (the first pair has 3 taps)
+  auto slots_of = [&](const int pp_, const int cc_) { return (itail && cc_ + 1 == cpc) ? nt : pair_taps(pp_); };   // MFMA groups of a chunk
+  int cbase = 0, gph = 0;                        // byte offset of the current chunk's first piece (a chunk always OWNS T pieces)
+  constexpr int PIECE = NP * RT * 1024;
+  {
+    const int s0 = slots_of(0, 0);
+    dma_w(0, (s0 < TPP ? s0 : TPP) * NP * RT, Ws);
+  }
   load_raw(true, 0, 0);
   publish_max(0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -779,32 +789,63 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
 
   for (int vc = 0; vc < NV; vc++) {
     const int pz = pp >> 1, py = pp & 1;
-    const int T = pair_taps(pp), nph = (T + TPP - 1) / TPP;
-    const int T_n = pair_taps(pp_n_of(pp, cc_cur));
+    const int T = pair_taps(pp);
+    const bool tailc = itail && cc_cur + 1 == cpc;
+    const int Tc = tailc ? nt : T;               // MFMA groups of this chunk
+    const int nph = (Tc + TPP - 1) / TPP;
     int cc_n = cc_cur + 1, pp_n = pp;
     if (cc_n == cpc) cc_n = 0, pp_n = pp + 1;
+    const int Tc_n = slots_of(pp_n > 3 ? 3 : pp_n, cc_n);
+    int goff[8];                                 // tail: halo offsets of the lane's 8 taps (K half lane >> 5) in this pair's list
+    if (tailc) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int kk = 8 * (lane >> 5) + i;
+        kk = kk < T ? kk : 0;                    // (beyond the list: any valid voxel, the weights are zero)
+        const int g = kk / 3, xt = kk - 3 * g;
+        const int iz = g >> py, iy = g & py;
+        goff[i] = (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+      }
+    }
     for (int ph = 0; ph < nph; ph++, gph++) {
       const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
-      const int ntap = T - TPP * ph < TPP ? T - TPP * ph : TPP;
-      const int wsize = ntap * NP * RT * 1024;
+      const int ntap = Tc - TPP * ph < TPP ? Tc - TPP * ph : TPP;
       const bool last = ph + 1 == nph;
-      const int ntap_n = last ? (T_n < TPP ? T_n : TPP) : (T - TPP * (ph + 1) < TPP ? T - TPP * (ph + 1) : TPP);
-      if (!(last && vc + 1 == NV)) dma_w(woff + wsize, ntap_n * NP * RT, Ws + ((gph + 1) & 1) * G::WBUF);
+      const int ntap_n = last ? (Tc_n < TPP ? Tc_n : TPP) : (Tc - TPP * (ph + 1) < TPP ? Tc - TPP * (ph + 1) : TPP);
+      const int woff_n = last ? cbase + T * PIECE : cbase + TPP * (ph + 1) * PIECE;
+      if (!(last && vc + 1 == NV)) dma_w(woff_n, ntap_n * NP * RT, Ws + ((gph + 1) & 1) * G::WBUF);
       __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
       if (ph == 0) load_raw(vc + 1 < NV, pp_n, cc_n);
 #pragma unroll
       for (int ix = 0; ix < TPP; ix++) {
         if (ix < ntap) {
-          const int t = TPP * ph + ix, g = t / 3, xt = t - 3 * g;   // tap of the list: (iz, iy) = g, x tap: k = 1 | 0 | 2
-          const int iz = g >> py, iy = g & py;
-          const unsigned char* Hk = Hs + (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+          const int t = TPP * ph + ix;     // tap of the pair's list (tail chunk: tail channel)
           h8 fa[NP][RT], fb[NP][2];
 #pragma unroll
-          for (int part = 0; part < NP; part++) {
+          for (int part = 0; part < NP; part++)
 #pragma unroll
             for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + ((ix * NP + part) * RT + i) * 1024);
+          if (tailc) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
+            for (int part = 0; part < NP; part++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) {
+                const unsigned char* hb = Hs + part * (2 * HPLANE) + (bbase[j] - (lane >> 5) * HPLANE) + t * 2;   // channel half 0, channel t
+                u32x4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  pk[k] = (unsigned)*reinterpret_cast<const unsigned short*>(hb + goff[2 * k]) |
+                          ((unsigned)*reinterpret_cast<const unsigned short*>(hb + goff[2 * k + 1]) << 16);
+                fb[part][j] = __builtin_bit_cast(h8, pk);
+              }
+          } else {
+            const int g = t / 3, xt = t - 3 * g;   // (iz, iy) = g, x tap: k = 1 | 0 | 2
+            const int iz = g >> py, iy = g & py;
+            const unsigned char* Hk = Hs + (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+#pragma unroll
+            for (int part = 0; part < NP; part++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) fb[part][j] = *reinterpret_cast<const h8*>(Hk + part * (2 * HPLANE) + bbase[j]);
           }
 #pragma unroll
           for (int i = 0; i < RT; i++)
@@ -832,8 +873,8 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      woff += wsize;
     }
+    cbase += T * PIECE;
     if (vc + 1 < NV) {
       const int s_next = next_scale((vc + 1) & 1, s_run);
       const bool turn = (((vc + 1) >> S2FLIP_SH) ^ (vc >> S2FLIP_SH)) & 1;
@@ -1184,6 +1225,7 @@ struct S2PackParams {
   _Float16* img;
   int Cout, Cin, kind, K, N, cpc, nblk, RT, n_off, mode;
   int bf;   // 1: one bf16 part per weight, unscaled
+  int itail;   // mode 3: the last chunk's 1 - 2 channels in im2col form (sr3d_hconv_s2_fwd_itail)
   int rbeg[SR3D_MAX_SRC + 1];
   int cbeg[SR3D_MAX_SRC];
 };
@@ -1214,9 +1256,12 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     const int cc = r % p.cpc;
     const int nb = r / p.cpc;
     int cls = 0, tl, tap, vc;
+    bool itc = false;   // im2col tail chunk of the paired forward: the item is (tail channel tl, K half h), element j = tap 8 h + j of the pair's list
     if (p.mode >= 3) {   // paired forward (3) / paired input gradient (4): `cls` = pair 2 pz + py, local tap = 3 (iz * ny + iy) + x tap (k = 1 | 0 | 2)
       while (cls < 3 && tg >= pair_taps_before(cls + 1)) cls++;
       tl = tg - pair_taps_before(cls);
+      itc = p.mode == 3 && p.itail != 0 && cc + 1 == p.cpc;
+      if (itc && tl >= (p.K & 15)) continue;
       const int pz = cls >> 1, py = cls & 1, g = tl / 3, xt = tl - 3 * g;
       const int iz = g >> py, iy = g & py;
       tap = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + (xt == 0 ? 1 : xt == 1 ? 0 : 2);
@@ -1249,14 +1294,21 @@ __global__ __launch_bounds__(256) void hconv_s2_pack_kernel(const S2PackParams p
     bf8 wb;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int k = cc * HKC + h * 8 + j;
+      int k = cc * HKC + h * 8 + j;
+      int tapj = tap;
+      if (itc) {   // (forward kinds only)
+        const int kk = 8 * h + j, pz = cls >> 1, py = cls & 1;
+        k = kk < pair_taps(cls) ? cc * HKC + tl : p.K;   // beyond the pair's list: zero
+        const int g = kk / 3, xt = kk - 3 * g, iz = g >> py, iy = g & py;
+        tapj = (tap_k(pz, iz) * 3 + tap_k(py, iy)) * 3 + (xt == 0 ? 1 : xt == 1 ? 0 : 2);
+      }
       float val = 0.f;
       if (w != nullptr && k < p.K) {
         if (p.kind == SR3D_PACK_BWD || p.kind == SR3D_PACK_BWD_GATED) {
           const float* src = k < p.Cout ? w + (long long)k * kstride : (p.w2 + (w - p.w1)) + (long long)(k - p.Cout) * kstride;
-          val = src[tap];
+          val = src[tapj];
         } else {
-          val = w[(long long)k * kstride + tap];
+          val = w[(long long)k * kstride + tapj];
         }
       }
       const float s = val * ((((vc >> S2FLIP_SH) & 1) && !p.bf) ? -w_mult : w_mult);
@@ -1320,6 +1372,8 @@ int set_attrs() {
 }  // namespace
 
 // forward: both x parities per load (pack order 3) when the rows can be fetched as quads; SR3D_HCONV_S2_CLASS_FWD=1 keeps the class form
+// paired forward: im2col tail for a last chunk of 1 - 2 channels (SR3D_HCONV_NO_ITAIL=1: off)
+bool sr3d_hconv_s2_fwd_itail(int K) { return (K & 15) >= 1 && (K & 15) <= 2 && getenv("SR3D_HCONV_NO_ITAIL") == nullptr; }
 bool sr3d_hconv_s2_fwd_paired(int IX) { return IX % 4 == 0 && getenv("SR3D_HCONV_S2_CLASS_FWD") == nullptr; }
 
 // input gradient: both x classes per workgroup (pack order 4, launch mode 4) when the dY rows can be fetched as quads;
@@ -1350,6 +1404,7 @@ int sr3d_hconv_s2_pack(int mode, int kind, int Cout, int Cin, int rows, int K, c
   }
   S2PackParams p{};
   p.bf = bf ? 1 : 0;
+  p.itail = (mode == 3 && sr3d_hconv_s2_fwd_itail(K)) ? 1 : 0;
   p.w1 = w1, p.w2 = w2, p.absmax_w = (const float*)hdr;
   p.Cout = Cout, p.Cin = Cin, p.kind = kind, p.K = K, p.N = rows, p.cpc = ceil_div(K, HKC), p.mode = mode;
   for (int i = 0; i <= SR3D_MAX_SRC; i++) p.rbeg[i] = rbeg ? rbeg[i] : INT_MAX;
@@ -1441,6 +1496,7 @@ int sr3d_hconv_s2_launch(int mode, SrHconvS2Params& p, const void* image, int B,
       continue;
     }
     if (mode == 1 && sr3d_hconv_s2_fwd_paired(p.IX)) {   // (the image was packed in pair order: sr3d_pack_weights asks the same question)
+      q.itail = sr3d_hconv_s2_fwd_itail(p.K) ? 1 : 0;
       for (int i = 0; i < p.in.n; i++)
         SR3D_CHECK((reinterpret_cast<uintptr_t>(p.in.ptr[i]) & (bf ? 7 : 15)) == 0, SR3D_E_ARG,
                    "stride-2 forward: x_srcs[%d] must be %d-byte aligned (X %% 4 == 0: rows are fetched as quads)", i, bf ? 8 : 16);
