@@ -11,7 +11,8 @@ import os
 import sys
 
 # substrings of the (demangled) kernel names in rocprofv3's counter CSV; first match wins
-FAMILIES = {"hwgrad_kernel": "hwgrad_kernel", "hconv_s2_kernel": "hconv_s2_kernel", "hconv_kernel": "hconv_kernel", "wino_wgrad_kernel": "wino_wgrad_kernel", "wino_kernel": "wino_kernel", "igemm_s2_fwd": "igemm_kernel<2,",
+FAMILIES = {"hwgrad_kernel": "hwgrad_kernel", "hwgrad_s2_kernel": "hwgrad_s2_kernel", "hwgrad_fc_kernel": "hwgrad_fc_kernel",
+            "hconv_s2_fwd_kernel": "hconv_s2_fwd_kernel", "hconv_s2_bwd_pair_kernel": "hconv_s2_bwd_pair_kernel", "hconv_s2_kernel": "hconv_s2_kernel", "hconv_kernel": "hconv_kernel", "wino_wgrad_kernel": "wino_wgrad_kernel", "wino_kernel": "wino_kernel", "igemm_s2_fwd": "igemm_kernel<2,",
             "igemm_s2_bwd": "igemm_kernel<1, 0,", "igemm_s1": "igemm_kernel<1, -1,", "wgrad_direct": "::wgrad_kernel<"}
 csv.field_size_limit(1 << 30)
 
