@@ -647,11 +647,12 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
     unsigned so[FNR];
 #pragma unroll
     for (int r = 0; r < FNR; r++) so[r] = ((fmask[r] >> pp) & 1u) ? fbase[r] + cdelta : 0xffffffffu;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int gc = cc * HKC + sh * 8 + c;   // wave-uniform
-      const unsigned long long base = chan_base(gc < p.K ? gc : p.K - 1);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && gc < p.K ? chan_bytes : 0, 0x00020000);
+    // (the usual case -- the wave's 8 channels lie in one tensor -- takes ONE slice lookup, behind a real branch: these kernels issue
+    //  11 scalar instructions per MFMA (profiles/r04bf_pmc_instruction_mix_down1_fp32.json) on the CU's one scalar unit, and the
+    //  per-channel lookups were a third of them)
+    const int g0 = cc * HKC + sh * 8;   // wave-uniform
+    auto loads = [&](const int c, const unsigned long long base) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live && g0 + c < p.K ? chan_bytes : 0, 0x00020000);
 #pragma unroll
       for (int r = 0; r < FNR; r++) {
         if constexpr (BF) {
@@ -664,6 +665,16 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
           for (int vx = 0; vx < 4; vx++) raw[r][c * 4 + vx] = __builtin_bit_cast(float, (unsigned)t[vx]);
         }
       }
+    };
+    const int first = g0 < p.K ? g0 : p.K - 1, last = g0 + 7 < p.K ? g0 + 7 : p.K - 1;
+    if (__builtin_expect(slice_of(first) == slice_of(last), 1)) {
+      unsigned long long base = chan_base(first);
+      split_pin_scalar(base);
+#pragma unroll
+      for (int c = 0; c < 8; c++) loads(c, base + (unsigned long long)c * (unsigned)chan_bytes);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; c++) loads(c, chan_base(g0 + c < p.K ? g0 + c : p.K - 1));
     }
   };
   // maxima: as in the class form (the pairs together see every element; a quad's columns beyond the halo belong to the same
@@ -998,6 +1009,8 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
   constexpr int RW = BF ? 8 : 16;    // fp32: [channel 0..3][voxel]; bf16: [channel][dword: voxels (0, 1) | (2, 3)]
   float rawq[QNR][RW];
   auto load_raw = [&](const bool live, const int cc) {
+    // (one slice lookup for the wave's 4 channels behind a branch, as in the paired forward, measured slightly SLOWER here:
+    //  profiles/r04bg_ab_s2_one_slice.log)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const int gc = cc * HKC + wave * 4 + c;   // wave-uniform
