@@ -807,6 +807,15 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
     int cc_n = cc_cur + 1, pp_n = pp;
     if (cc_n == cpc) cc_n = 0, pp_n = pp + 1;
     const int Tc_n = slots_of(pp_n > 3 ? 3 : pp_n, cc_n);
+    // lane t of `hktab`: halo byte offset of tap t of this pair's list (plane set of its x class, (hz, hy, hx)); a tap of the
+    // phase loop then costs ONE v_readlane instead of ~20 scalar instructions of decoding (t / 3, parities, tap_h ...)
+    int hktab;
+    {
+      const int kk = lane < T ? lane : 0;
+      const int g = kk / 3, xt = kk - 3 * g;
+      const int iz = g >> py, iy = g & py;
+      hktab = (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+    }
     int goff[8];                                 // tail: halo offsets of the lane's 8 taps (K half lane >> 5) in this pair's list
     if (tailc) {
 #pragma unroll
@@ -850,9 +859,7 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
                 fb[part][j] = __builtin_bit_cast(h8, pk);
               }
           } else {
-            const int g = t / 3, xt = t - 3 * g;   // (iz, iy) = g, x tap: k = 1 | 0 | 2
-            const int iz = g >> py, iy = g & py;
-            const unsigned char* Hk = Hs + (xt != 0 ? G::PXB : 0) + ((tap_h(1, pz, iz) * HHY + tap_h(1, py, iy)) * HHX + (xt == 1 ? 0 : 1)) * 16;
+            const unsigned char* Hk = Hs + __builtin_amdgcn_readlane(hktab, t);   // (t is wave-uniform)
 #pragma unroll
             for (int part = 0; part < NP; part++)
 #pragma unroll
