@@ -26,6 +26,12 @@
 #ifndef S2F_WGS_BF
 #define S2F_WGS_BF 3
 #endif
+#ifndef S2B_GPP_BF
+#define S2B_GPP_BF 2
+#endif
+#ifndef S2B_GPP_F32
+#define S2B_GPP_F32 2
+#endif
 
 namespace {
 
@@ -935,7 +941,11 @@ __global__ __launch_bounds__(HNT, BF ? S2F_WGS_BF : 2) void hconv_s2_fwd_kernel(
 template <int RT, bool BF>
 struct PGeo {
   static constexpr int NP = BF ? 1 : 2;
-  static constexpr int WBUF = 3 * NP * RT * 1024;   // one phase: the three x taps of a (kz, ky)
+  // (kz, ky) groups of three x taps per phase (= per barrier, weight DMA, wait): two -- with one group per phase the waves stood
+  // parked at barriers a third (bf16: half) of the time (PMC, profiles/r04bf_*.json); down1.0 3.88 -> 3.76 ms fp32, 2.31 -> 2.26 ms
+  // bf16 (profiles/r04bm_ab_s2_bwd_groups_per_phase.log).  Split form: 32 + 48 KB of LDS, still two workgroups per CU.
+  static constexpr int GPP = BF ? S2B_GPP_BF : S2B_GPP_F32;
+  static constexpr int WBUF = GPP * 3 * NP * RT * 1024;
   static constexpr int HB = NP * 2 * HPLANE;
   static constexpr size_t LDS = HB + 2 * (size_t)WBUF;
 };
@@ -1079,15 +1089,16 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
       }
   };
 
-  const int T = pair_taps(pq), nph = T / 3;      // phases of a chunk: the (kz, ky) of the pair
+  constexpr int GPP = G::GPP;
+  const int T = pair_taps(pq), ngr = T / 3, nph = (ngr + GPP - 1) / GPP;   // (kz, ky) groups of the pair; phases of a chunk
   const long long blk_bytes = (long long)p.nchunks * T * NP * RT * 1024;
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wimg) + p.cls_off[pq] + (size_t)(p.nb_off + nblk) * blk_bytes;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)blk_bytes, 0x00020000);
-  auto dma_w = [&](const int woff, unsigned char* W) {
+  auto dma_w = [&](const int woff, const int ngroups, unsigned char* W) {
 #pragma unroll
-    for (int ii = 0; ii < (3 * NP * RT + 3) / 4; ii++) {
+    for (int ii = 0; ii < (GPP * 3 * NP * RT + 3) / 4; ii++) {
       const int i = wave + 4 * ii;
-      if (i < 3 * NP * RT) split_lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
+      if (i < ngroups * 3 * NP * RT) split_lds_dma16(wrs, (lds_p)(W + i * 1024), woff + i * 1024 + lane * 16);
     }
   };
 
@@ -1107,10 +1118,10 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
     bbase[j] = (lane >> 5) * HPLANE + (((vt >> 2) * HHY + (vt & 3)) * HHX + (lane & 31)) * 16;
   }
   const int abase = lane * 16;
-  constexpr int WSIZE = 3 * NP * RT * 1024;
+  constexpr int GSIZE = 3 * NP * RT * 1024;   // bytes of one group's weights
 
   int woff = 0, gph = 0;
-  dma_w(0, Ws);
+  dma_w(0, ngr < GPP ? ngr : GPP, Ws);
   load_raw(true, 0);
   publish_max(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1124,11 +1135,18 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
     for (int ph = 0; ph < nph; ph++, gph++) {
       const unsigned char* W = Ws + (gph & 1) * G::WBUF + abase;
       const bool last = ph + 1 == nph;
-      if (!(last && vc + 1 == NV)) dma_w(woff + WSIZE, Ws + ((gph + 1) & 1) * G::WBUF);
+      const int ng = ngr - GPP * ph < GPP ? ngr - GPP * ph : GPP;                       // groups of this phase
+      const int ng_n = last ? (ngr < GPP ? ngr : GPP) : (ngr - GPP * (ph + 1) < GPP ? ngr - GPP * (ph + 1) : GPP);
+      if (!(last && vc + 1 == NV)) dma_w(woff + ng * GSIZE, ng_n, Ws + ((gph + 1) & 1) * G::WBUF);
       __builtin_amdgcn_sched_barrier(0);   // (the wait below counts on the DMA being older than the raw rows)
       if (ph == 0) load_raw(vc + 1 < NV, vc + 1);
-      const int iz = ph >> qy, iy = ph & qy;   // ph = iz * (1 + qy) + iy
+#pragma unroll
+      for (int gs = 0; gs < GPP; gs++) {
+      if (gs >= ng) break;
+      const int gi = ph * GPP + gs;            // group = iz * (1 + qy) + iy
+      const int iz = gi >> qy, iy = gi & qy;
       const unsigned char* Hk = Hs + ((tap_h(2, qz, iz) * HHY + tap_h(2, qy, iy)) * HHX) * 16;
+      const unsigned char* Wg = W + gs * GSIZE;
       // x taps: 0: k = 1, even x, dy[i]; 1: k = 0, odd x, dy[i + 1]; 2: k = 2, odd x, dy[i]
 #pragma unroll
       for (int hx = 0; hx < 2; hx++) {
@@ -1144,7 +1162,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
 #pragma unroll
           for (int part = 0; part < NP; part++)
 #pragma unroll
-            for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(W + ((xt * NP + part) * RT + i) * 1024);
+            for (int i = 0; i < RT; i++) fa[part][i] = *reinterpret_cast<const h8*>(Wg + ((xt * NP + part) * RT + i) * 1024);
           const int cx = xt == 0 ? 0 : 1;
 #pragma unroll
           for (int i = 0; i < RT; i++)
@@ -1161,6 +1179,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
             }
         }
       }
+      }   // gs
       if (last && vc + 1 < NV) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish_max((vc + 1) & 1);
@@ -1171,7 +1190,7 @@ __global__ __launch_bounds__(HNT, 2) void hconv_s2_bwd_pair_kernel(const SrHconv
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      woff += WSIZE;
+      woff += ng * GSIZE;
     }
     if (vc + 1 < NV) {
       const int s_next = next_scale((vc + 1) & 1, s_run);
